@@ -1,0 +1,111 @@
+"""Pins the CPU oracle (oracle/vtoonify_oracle.py) against tensors computed by the REAL
+reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: upfirdn2d on integer-valued inputs with dyadic FIR taps is BIT-EXACT (every
+partial sum is exactly representable, so summation order is irrelevant); everything
+else is fp32 with a different summation order than torch's CPU kernels: 2e-5 relative
+to the tensor's max-abs (measured ~1e-6).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_keys, rel_err
+from oracle import vtoonify_oracle as O
+from vtoonify_amd import synth
+
+TOL = 2e-5
+
+
+def test_upfirdn2d_all_cases():
+    d, meta = load_golden("op_upfirdn2d.npz")
+    assert len(meta) >= 12
+    for m in meta:
+        n = m["name"]
+        up = tuple(m["up"]) if isinstance(m["up"], list) else m["up"]
+        down = tuple(m["down"]) if isinstance(m["down"], list) else m["down"]
+        y = O.upfirdn2d(d[n + "__x"], d[n + "__k"], up=up, down=down, pad=tuple(m["pad"]))
+        ref = d[n + "__y"]
+        assert y.shape == ref.shape, n
+        if m["integer"]:
+            assert np.array_equal(y, ref), f"{n}: not bit-exact"
+        else:
+            assert rel_err(y, ref) < 1e-6, n
+
+
+def test_fused_leaky_relu_bit_exact():
+    d, meta = load_golden("op_fused_act.npz")
+    for m in meta:
+        n = m["name"]
+        b = d.get(n + "__b")
+        y = O.fused_leaky_relu(d[n + "__x"], b, m["slope"], m["scale"])
+        assert np.array_equal(y, d[n + "__y"]), n
+
+
+def _sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix) and "__" not in k}
+
+
+def test_modules():
+    d, _ = load_golden("modules.npz")
+    # StyledConv up / same
+    for name, up in [("sc_up", True), ("sc_same", False)]:
+        sd = _sub(d, name + ".")
+        conv = O.modulated_conv2d(d[name + "__x"], d[name + "__s"], sd["conv.weight"],
+                                  sd["conv.modulation.weight"], sd["conv.modulation.bias"],
+                                  True, up, sd.get("conv.blur.kernel"))
+        assert rel_err(conv, d[name + "__conv"]) < TOL
+        y = O.styled_conv({name + "." + k: v for k, v in sd.items()}, name + ".", d[name + "__x"],
+                          d[name + "__s"], up)
+        assert rel_err(y, d[name + "__y"]) < TOL
+    sd = {k: v for k, v in d.items() if k.startswith("rgb.")}
+    y = O.to_rgb(sd, "rgb.", d["rgb__x"], d["rgb__s"], d["rgb__skip"])
+    assert rel_err(y, d["rgb__y"]) < TOL
+    assert rel_err(O.to_rgb(sd, "rgb.", d["rgb__x"], d["rgb__s"], None), d["rgb__y_noskip"]) < TOL
+    # EqualLinear
+    y = O.equal_linear(d["el_plain__x"], d["el_plain.weight"], d["el_plain.bias"], 1.0, False)
+    assert rel_err(y, d["el_plain__y"]) < TOL
+    y = O.equal_linear(d["el_act__x"], d["el_act.weight"], d["el_act.bias"], 0.01, True)
+    assert rel_err(y, d["el_act__y"]) < TOL
+    # AdaResBlock
+    for dil in (1, 2, 4):
+        n = f"ada_d{dil}"
+        sd = {k: v for k, v in d.items() if k.startswith(n + ".")}
+        y = O.ada_res_block(sd, n + ".", d[n + "__x"], d[n + "__s"], 0.7, dil)
+        assert rel_err(y, d[n + "__y"]) < TOL, n
+        assert np.array_equal(O.ada_res_block(sd, n + ".", d[n + "__x"], d[n + "__s"], 0, dil),
+                              d[n + "__y0"])
+    sd = {k: v for k, v in d.items() if k.startswith("vres.")}
+    assert rel_err(O.vtoonify_res_block(sd, "vres.", d["vres__x"]), d["vres__y"]) < TOL
+    sd = {k: v for k, v in d.items() if k.startswith("fus.")}
+    f_out, m_e = O.fusion(sd, "fus.", d["fus__fg"], d["fus__fe"], 0.6)
+    assert rel_err(f_out, d["fus__out"]) < TOL
+    assert rel_err(m_e, d["fus__mask"]) < TOL
+    k = synth.fir_kernel_2d().numpy()
+    assert rel_err(O.upfirdn2d(d["mod_up__x"], k * 4, up=2, pad=tuple(d["mod_up__pad"])),
+                   d["mod_up__y"]) < 1e-6
+    assert rel_err(O.upfirdn2d(d["mod_up__x"], k, down=2, pad=tuple(d["mod_dn__pad"])),
+                   d["mod_dn__y"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,bb", [("D", "dualstylegan"), ("T", "toonify")])
+def test_end_to_end(tag, bb):
+    d, _ = load_golden(f"e2e_{tag}.npz")
+    shapes = load_keys(tag)
+    assert len(shapes) == (399 if tag == "D" else 229)
+    sd = synth.to_numpy_sd(synth.synth_state_dict(shapes, 0))
+    x, s = d["x"], d["style"]
+    for key in [k for k in d if k.startswith("y_ds")]:
+        d_s = float(key[4:])
+        y = O.vtoonify_forward(sd, x, s, d_s, bb)
+        assert y.shape == (1, 3, 128, 128)
+        assert rel_err(y, d[key]) < TOL, key
+    feat, skip = O.vtoonify_forward(sd, x, s, 0.5, bb, return_feat=True)
+    assert rel_err(feat, d["feat_ds0.5"]) < TOL and rel_err(skip, d["skip_ds0.5"]) < TOL
+    if tag == "D":
+        _, masks = O.vtoonify_forward(sd, x, s, 0.5, bb, return_mask=True)
+        for i, m in enumerate(masks):
+            assert rel_err(m, d[f"mask{i}_ds0.5"]) < TOL
+    assert rel_err(O.vtoonify_forward(sd, x, s[:, 3], 0.5, bb), d["y_wspace"]) < TOL
+    y2 = O.vtoonify_forward(sd, d["x2"], d["style2"], 0.75, bb)
+    assert rel_err(y2, d["y2_ds0.75"]) < TOL
+    assert rel_err(O.zplus2wplus(sd, d["zplus"], bb), d["wplus"]) < TOL
