@@ -1,0 +1,200 @@
+/*
+ * vtoonify_amd.h -- C ABI of libvtoonify_amd.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for VToonify's per-frame inference hot path
+ * (williamyang1991/VToonify, model/vtoonify.py:210-277).  The reference reaches its
+ * native code through two pybind11 modules JIT-built from CUDA sources:
+ *
+ *   upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y,
+ *                          pad_x0, pad_x1, pad_y0, pad_y1)   model/stylegan/op/upfirdn2d.cpp:17-31
+ *   fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *                                                           model/stylegan/op/fused_bias_act.cpp:18-32
+ *
+ * and through cuDNN (F.conv2d / F.conv_transpose2d, model/stylegan/op/conv2d_gradfix.py:22-75).
+ * The entry points below replace exactly those, plus the frame-invariant style maths
+ * (ModulatedConv2d weight modulation, model/stylegan/model.py:259-267) and the
+ * normalisation glue that the reference runs as eager aten ops.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw DEVICE pointers, sizes, a hipStream_t passed as void*
+ *   - every call is asynchronous on `stream`, never synchronises, never allocates
+ *   - inputs are borrowed, outputs are caller-allocated (the Python layer allocates
+ *     them, mirroring at::empty in upfirdn2d_kernel.cu:242 / fused_bias_act_kernel.cu:94)
+ *   - return 0 on success, a VT_ERR_* code otherwise (vt_last_error() has the text);
+ *     nothing throws
+ *   - dtype codes: activations/weights may be fp32, bf16 or fp16 where noted; all
+ *     accumulation is fp32
+ */
+#ifndef VTOONIFY_AMD_H
+#define VTOONIFY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_ABI_VERSION 1
+
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
+enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
+
+/* activation codes of the fused epilogues */
+enum { VT_ACT_NONE = 0, VT_ACT_LRELU = 1, VT_ACT_RELU_TANH = 2 };
+/* output layouts of vt_conv2d */
+enum { VT_OUT_NHWC = 0, VT_OUT_NCHW = 1 };
+
+typedef void* vt_stream; /* hipStream_t */
+
+int vt_abi_version(void);
+const char* vt_last_error(void);
+/* "gfx950" for the product build */
+const char* vt_build_target(void);
+
+/* ---------------------------------------------------------------------------------
+ * upfirdn2d -- replaces upfirdn2d_op.upfirdn2d (op/upfirdn2d.cpp:17-31,
+ * upfirdn2d_kernel.cu:209-369).  `in` is `planes` contiguous (in_h, in_w) images (the
+ * Python side folds N*C into planes exactly like op/upfirdn2d.py:100 with minor=1);
+ * `fir` is the un-flipped (kh, kw) fp32 kernel (the flip of upfirdn2d_kernel.cu:137 is
+ * applied inside).  out_h/out_w follow op/upfirdn2d.py:104-105 and are returned by
+ * vt_upfirdn2d_out_size.  dtype: VT_F32 / VT_BF16 / VT_F16 (fp32 accumulate).
+ * --------------------------------------------------------------------------------- */
+int vt_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                          int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                          int pad_y1, int* out_h, int* out_w);
+int vt_upfirdn2d(void* out, const void* in, const float* fir, int64_t planes, int in_h,
+                 int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, int dtype,
+                 vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * fused_bias_act -- replaces fused.fused_bias_act (op/fused_bias_act.cpp:18-32,
+ * fused_bias_act_kernel.cu:18-105):  y = act(x + b[(i / step_b) % size_b]) * scale with
+ * act*10+grad in {10,11,12,30,31,32} (kernel.cu:40-61).  `bias` / `refer` may be NULL
+ * ("empty tensor" in the reference).  bias has the dtype of x.
+ * --------------------------------------------------------------------------------- */
+int vt_fused_bias_act(void* out, const void* x, const void* bias, const void* refer,
+                      int64_t numel, int64_t step_b, int size_b, int act, int grad,
+                      float alpha, float scale, int dtype, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * Dense contraction -- replaces every F.conv2d / F.conv_transpose2d / nn.Conv2d on the
+ * path (op/conv2d_gradfix.py:34-42,66-75; model/vtoonify.py:96-97,111-113,162-198) with
+ * one implicit-GEMM MFMA kernel family.
+ *
+ * Activations are NHWC.  The input may be the channel concatenation of two tensors
+ * (torch.cat of model/vtoonify.py:125,127,259) given as two (pointer, channels, pixel
+ * stride) triples.  Weights are packed [cout_total][kh*kw][cin] in the compute dtype
+ * (vt_pack_conv_weight / vt_modulate_weight produce that layout).
+ *
+ *   acc   = sum_{tap,c} in[n, oy*stride + ky*dil - pad, ox*stride + kx*dil - pad, c] * w[co,tap,c]
+ *   v     = act(acc + bias[co]) * gain * alpha * (alpha_dev ? *alpha_dev : 1)
+ *   out   = v + beta * resid
+ *
+ * phases == 4: "up-sampling StyledConv" form.  cout_total = 4*cout, output column
+ * p*cout+co of input-grid pixel (y,x) is stored at pixel (2y + p/2, 2x + p%2) of a
+ * (2h, 2w) image: conv_transpose2d(stride 2) followed by the 4x4 FIR blur
+ * (model/stylegan/model.py:273-286) collapses into four 3x3 polyphase filters.
+ * transposed != 0: gather form of F.conv_transpose2d (used by the generic
+ * conv2d_gradfix.conv_transpose2d entry point only).
+ * --------------------------------------------------------------------------------- */
+typedef struct vt_conv_desc {
+    const void* src0;      /* NHWC, dtype `dtype` */
+    const void* src1;      /* second concat source or NULL */
+    int32_t c0, c1;        /* channels read from src0 / src1 (multiples of 8) */
+    int32_t ld0, ld1;      /* per-pixel stride of each source, in elements */
+    int32_t n, h, w;       /* input batch / height / width */
+    int32_t out_h, out_w;  /* conv output size (before the x2 of phases==4) */
+    const void* weight;    /* [phases*cout][kh*kw][c0+c1], dtype `dtype` */
+    int32_t cout;
+    int32_t kh, kw, stride, pad, dil;
+    int32_t phases;        /* 1 or 4 */
+    int32_t transposed;    /* 0 or 1 */
+    const float* in_scale; /* optional per-(n, cin) affine prologue (AdaIN):   */
+    const float* in_shift; /*   x' = x * in_scale[n][c] + in_shift[n][c]; NULL = off */
+    const float* bias;     /* [cout] fp32 or NULL */
+    int32_t act;           /* VT_ACT_* */
+    float slope, gain, alpha, beta;
+    const float* alpha_dev; /* optional device scalar (style degree d_s) */
+    const void* resid;     /* same layout/dtype as out, or NULL */
+    int32_t ld_res;
+    void* out;
+    int32_t ld_out;        /* NHWC: per-pixel stride in elements; NCHW: ignored */
+    int32_t out_layout;    /* VT_OUT_NHWC / VT_OUT_NCHW */
+    int32_t out_dtype;     /* VT_F32 / VT_BF16 (NCHW output is always fp32) */
+    int32_t dtype;         /* VT_F32 / VT_BF16: dtype of src*, weight */
+    int32_t tile_hint;     /* 0 = auto; otherwise BM*1000+BN of a compiled tile */
+} vt_conv_desc;
+
+int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
+
+/* Plain conv weight (cout, cin_src, kh, kw) fp32 -> packed [cout][kh*kw][cin_dst],
+ * multiplied by `scale` (EqualConv2d's 1/sqrt(fan_in), model/stylegan/model.py:101,117).
+ * chan_map[cin_dst] (device int32) gives the source channel of each packed channel, -1
+ * for zero padding; NULL = identity.  src_transposed: source is (cin_src, cout, kh, kw)
+ * as F.conv_transpose2d expects; spatial taps are flipped for the gather form. */
+int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_src, int kh, int kw,
+                        int cin_dst, const int32_t* chan_map, float scale,
+                        int src_transposed, int out_dtype, vt_stream stream);
+
+/* ModulatedConv2d weight path (model/stylegan/model.py:259-267):
+ *   w'[co,ci,a,b] = scale * weight[co,ci,a,b] * s[ci];  demod: w' *= rsqrt(sum w'^2 + 1e-8)
+ * (one wavefront per output channel, shuffle reduction over cin*k*k).
+ * fir == NULL : packed [cout][k*k][cin]
+ * fir != NULL : (4,4) blur taps; k must be 3; packed [4*cout][9][cin] polyphase weights
+ *               of conv_transpose2d(stride 2) + Blur(pad (1,1)) (model.py:273-286). */
+int vt_modulate_weight(void* out, const float* weight, const float* s, int cout, int cin,
+                       int k, float scale, int demodulate, const float* fir,
+                       int out_dtype, vt_stream stream);
+
+/* y[r, o] = act(sum_i x[r,i] * W[o,i] * w_scale + b[o] * b_scale)
+ * EqualLinear (model/stylegan/model.py:152-162), nn.Linear (dualstylegan.py:11,
+ * vtoonify.py:114-119).  act: VT_ACT_NONE or VT_ACT_LRELU with (slope, gain).  fp32.
+ * One wavefront per output, shuffle reduction. */
+int vt_linear(float* y, int ld_y, const float* x, int ld_x, const float* W, const float* b,
+              int rows, int in_dim, int out_dim, float w_scale, float b_scale, int act,
+              float slope, float gain, vt_stream stream);
+
+/* PixelNorm (model/stylegan/model.py:17-18) on (rows, dim) fp32. */
+int vt_pixel_norm(float* y, const float* x, int rows, int dim, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * InstanceNorm / AdaIN (model/dualstylegan.py:6-21) on NHWC activations.
+ * vt_instnorm_stats accumulates deterministic per-chunk (count, mean, M2) partials and
+ * reduces them to scale/shift such that AdaIN(x) = x * scale[n][c] + shift[n][c]:
+ *   scale = gamma * rstd,  shift = beta - gamma * rstd * mean   (eps 1e-5, biased var)
+ * gamma/beta come from `style_gb` = Linear(style) laid out [n][2*C] (gamma first).
+ * If `absdiff_other` != NULL the tensor normalised is cat[x, |x - other|] (Fusion,
+ * model/vtoonify.py:125): C counts the channels of x, stats cover 2*C channels.
+ * `partials` is caller workspace of vt_instnorm_ws_bytes(...) bytes.
+ * --------------------------------------------------------------------------------- */
+int64_t vt_instnorm_ws_bytes(int n, int hw, int c_total);
+int vt_instnorm_stats(float* scale, float* shift, const void* x, int ld_x,
+                      const void* absdiff_other, int ld_other, int n, int hw, int c,
+                      const float* style_gb, int ld_gb, void* partials, int dtype,
+                      vt_stream stream);
+/* out[p][c] = x*scale+shift  (and the |x-other| half when absdiff_other != NULL). */
+int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
+                    const void* absdiff_other, int ld_other, const float* scale,
+                    const float* shift, int n, int hw, int c, int dtype, vt_stream stream);
+
+/* Fusion glue (model/vtoonify.py:127, 259): out[p] = [skip(3) | 0 x5 | f_e[p][:] * m[p]]
+ * with per-pixel stride ld_out >= 8 + c.  skip is NCHW fp32 (n,3,h,w); mask (n,h,w) fp32
+ * (NULL = 1, the Toonify backbone, vtoonify.py:262). */
+int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float* mask,
+                   const float* skip, int n, int hw, int c, int dtype, vt_stream stream);
+
+/* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
+int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,
+                    int in_dtype, int out_dtype, vt_stream stream);
+int vt_nhwc_to_nchw(void* out, const void* in, int ld_in, int n, int c, int hw,
+                    int in_dtype, int out_dtype, vt_stream stream);
+
+/* MFMA fragment-layout self test: C = A(16xK) * B(KxN)^T on one wavefront, used by the
+ * GPU test-suite to pin the 16x16x32 bf16 / 16x16x4 f32 lane maps on real hardware. */
+int vt_mfma_selftest(float* c, const void* a, const void* b, int dtype, vt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTOONIFY_AMD_H */

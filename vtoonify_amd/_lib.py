@@ -1,0 +1,131 @@
+"""ctypes binding of libvtoonify_amd.so -- the C ABI of include/vtoonify_amd.h.
+
+The product loads exactly one library: vtoonify_amd/lib/libvtoonify_amd.so built for
+gfx950 by `python -m vtoonify_amd.build`.  If it is missing this module raises -- there is
+no CPU / eager-PyTorch fallback anywhere in the package.
+
+(Tests may inject the host-emulation build of the same sources with `use_library(path)`;
+that path is never consulted implicitly.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
+
+VT_F32, VT_BF16, VT_F16 = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_RELU_TANH = 0, 1, 2
+OUT_NHWC, OUT_NCHW = 0, 1
+
+
+class VtError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32),
+        ("weight", C.c_void_p),
+        ("cout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("dil", C.c_int32),
+        ("phases", C.c_int32), ("transposed", C.c_int32),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("act", C.c_int32),
+        ("slope", C.c_float), ("gain", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+        ("alpha_dev", C.c_void_p),
+        ("resid", C.c_void_p), ("ld_res", C.c_int32),
+        ("out", C.c_void_p), ("ld_out", C.c_int32),
+        ("out_layout", C.c_int32), ("out_dtype", C.c_int32), ("dtype", C.c_int32),
+        ("tile_hint", C.c_int32),
+    ]
+
+
+_SIGS = {
+    "vt_abi_version": (C.c_int, []),
+    "vt_last_error": (C.c_char_p, []),
+    "vt_build_target": (C.c_char_p, []),
+    "vt_upfirdn2d_out_size": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_int)] * 2),
+    "vt_upfirdn2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 12 +
+                     [C.c_int, C.c_void_p]),
+    "vt_fused_bias_act": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                       C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "vt_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "vt_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "vt_modulate_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vt_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                            C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                            C.c_void_p]),
+    "vt_pixel_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vt_instnorm_ws_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "vt_instnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p]),
+    "vt_affine_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
+    "vt_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
+    "vt_mfma_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+_lib_path = None
+
+
+def _bind(path: str):
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vt_abi_version() != 1:
+        raise VtError(f"{path}: ABI version {lib.vt_abi_version()} != 1")
+    return lib
+
+
+def use_library(path: str):
+    """Bind an explicit library file (tests: the host-emulation build)."""
+    global _lib, _lib_path
+    _lib = _bind(path)
+    _lib_path = path
+    return _lib
+
+
+def lib():
+    global _lib, _lib_path
+    if _lib is None:
+        if not os.path.exists(DEFAULT_LIB):
+            raise VtError(
+                f"{DEFAULT_LIB} is missing: the gfx950 HIP library has not been built. Run "
+                "`python -m vtoonify_amd.build` (needs hipcc). vtoonify_amd has no CPU fallback.")
+        _lib = _bind(DEFAULT_LIB)
+        _lib_path = DEFAULT_LIB
+    return _lib
+
+
+def lib_path():
+    lib()
+    return _lib_path
+
+
+def is_emulation() -> bool:
+    return lib().vt_build_target() != b"gfx950"
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise VtError(f"{what} failed (code {rc}): {lib().vt_last_error().decode()}")

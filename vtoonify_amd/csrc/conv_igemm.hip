@@ -1,0 +1,512 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores -- every dense contraction of the
+// VToonify frame (reference: F.conv2d / F.conv_transpose2d behind
+// model/stylegan/op/conv2d_gradfix.py:22-75 and the nn.Conv2d modules of
+// model/vtoonify.py:96-97,111-113,162-198; cuDNN in the reference).
+//
+// GEMM view (NHWC activations, weights packed [cout][tap][cin]):
+//     D[m, n] = sum_k A[m, k] * B[n, k]
+//     m = output pixel (n_img, oy, ox)          M = N*Ho*Wo
+//     n = output channel (x4 polyphase filters) Ncols = phases*cout
+//     k = (tap, cin)                            K = kh*kw*(c0+c1)
+// Both operands are K-contiguous, so every lane feeds the MFMA straight from 16-byte LDS
+// reads: bf16 uses v_mfma_f32_16x16x32_bf16 (8 consecutive k per lane), fp32 uses
+// v_mfma_f32_16x16x4_f32 x4 on the same 16 bytes (4 consecutive k per lane; the k-slot
+// permutation is identical for A and B so the dot product is unchanged).  fp32 mode is
+// exact fp32 (fmaf chain) and exists for parity against the fp32 reference.
+//
+// Workgroup = 256 threads = 4 wavefronts computing a BM x BN tile; K advances in steps of
+// 128 bytes per row (64 bf16 / 32 fp32).  Tiles are register-staged (global -> VGPR ->
+// LDS), double buffered, one barrier per K-step: the global loads of step t+1 are issued
+// before the MFMAs of step t.  LDS rows are 128 B with the 16-byte slot XOR-swizzled by
+// (row & 7): conflict-free for the ds_read_b128 lane groups and for the 8-lane
+// ds_write_b128 groups (MI355X_MICROARCH.md, LDS table).
+//
+// The im2col gather, zero padding, channel concatenation of two sources (torch.cat in
+// Fusion, model/vtoonify.py:125-127), the optional per-(n,cin) AdaIN affine
+// (model/dualstylegan.py:16-21) and the K tail are all resolved in the loader; the
+// epilogue (bias, LeakyReLU / relu-tanh, gain, style-degree scaling, residual add,
+// pixel-shuffle for the polyphase up-sampling conv, NHWC or planar NCHW stores) runs
+// from an LDS-staged fp32 tile so every global store is a full 16-byte vector.
+#include "vt_common.hpp"
+
+namespace {
+
+#ifdef VT_EMU
+typedef emu_f32x4 f32x4;
+#else
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#endif
+
+struct ConvArgs {
+    const void* src0;
+    const void* src1;
+    const void* wgt;
+    const float* bias;
+    const float* alpha_dev;
+    const float* in_scale;
+    const float* in_shift;
+    const void* resid;
+    void* out;
+    int c0, c1, ld0, ld1, cin;
+    int N, H, W, Ho, Wo;
+    int coutT, cout, K, taps, kw;
+    int stride, pad, dil, transposed, phases;
+    int act;
+    float slope, gain_alpha, beta;
+    int ld_res, ld_out, out_layout, out_f32, vec_store;
+    int M, tiles_n;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u128& a, const u128& b) {
+#ifdef VT_EMU
+        emu_bf16x8 av, bv;
+        memcpy(&av, &a, 16);
+        memcpy(&bv, &b, 16);
+        acc = emu_mfma_f32_16x16x32_bf16(av, bv, acc);
+#else
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+#endif
+    }
+};
+template <>
+struct Mma<float> {
+    static __device__ __forceinline__ void run(f32x4& acc, const u128& a, const u128& b) {
+#ifdef VT_EMU
+        acc = emu_mfma_f32_16x16x4f32(vt_u2f(a.x), vt_u2f(b.x), acc);
+        acc = emu_mfma_f32_16x16x4f32(vt_u2f(a.y), vt_u2f(b.y), acc);
+        acc = emu_mfma_f32_16x16x4f32(vt_u2f(a.z), vt_u2f(b.z), acc);
+        acc = emu_mfma_f32_16x16x4f32(vt_u2f(a.w), vt_u2f(b.w), acc);
+#else
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt_u2f(a.x), vt_u2f(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt_u2f(a.y), vt_u2f(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt_u2f(a.z), vt_u2f(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vt_u2f(a.w), vt_u2f(b.w), acc, 0, 0, 0);
+#endif
+    }
+};
+
+// x' = x * scale + shift on one 16-byte vector (AdaIN prologue)
+template <typename T>
+__device__ __forceinline__ u128 affine16(u128 v, const float* sc, const float* sh) {
+    constexpr int VEC = 16 / sizeof(T);
+    float f[VEC];
+    unpack16<T>(v, f);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = f[i] * sc[i] + sh[i];
+    return pack16<T>(f);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+conv_igemm_kernel(const ConvArgs p) {
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte vector
+    constexpr int BK = 8 * VEC;          // elements per 128-byte tile row
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert(TM >= 1 && TN >= 1, "wave tile too small");
+    constexpr int AI = (BM + 31) / 32, BI = (BN + 31) / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int SROWS = WM * 16, SLD = BN + 4;
+    static_assert(SROWS * SLD * 4 <= 2 * (A_BYTES + B_BYTES), "epilogue staging must fit");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    // buffer b lives at smem + b*(A_BYTES+B_BYTES): [A tile | B tile]
+    auto sA = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES); };
+    auto sB = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = blockIdx.x;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- loader state -----------------------------------------------------------
+    const int j = tid & 7, rbase = tid >> 3;
+    int a_pix[AI], a_y[AI], a_x[AI], a_img[AI];
+    bool a_ok[AI];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = rbase + 32 * i;
+        const int m = m0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
+        const int mm = a_ok[i] ? m : 0;
+        const int img = mm / HoWo;
+        const int rem = mm - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_img[i] = img;
+        a_pix[i] = img * p.H * p.W;
+        a_y[i] = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
+        a_x[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
+    }
+    int kc = j * VEC, tap = 0;
+    while (kc >= p.cin) {
+        kc -= p.cin;
+        ++tap;
+    }
+
+    const T* src0 = (const T*)p.src0;
+    const T* src1 = (const T*)p.src1;
+    const T* wgt = (const T*)p.wgt;
+
+    u128 ra[AI], rb[BI];
+    auto load_tiles = [&]() {
+        const bool tap_ok = tap < p.taps;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const int dy = ky * p.dil, dx = kx * p.dil;
+        const T* sp;
+        int ld, cc;
+        if (kc < p.c0) {
+            sp = src0; ld = p.ld0; cc = kc;
+        } else {
+            sp = src1; ld = p.ld1; cc = kc - p.c0;
+        }
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            u128 v = zero128();
+            if (a_ok[i] && tap_ok) {
+                int iy, ix;
+                bool in;
+                if (!p.transposed) {
+                    iy = a_y[i] + dy;
+                    ix = a_x[i] + dx;
+                    in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                } else {
+                    const int ty = a_y[i] - dy, tx = a_x[i] - dx;
+                    in = ty >= 0 && tx >= 0 && (ty % p.stride) == 0 && (tx % p.stride) == 0;
+                    iy = ty / p.stride;
+                    ix = tx / p.stride;
+                    in = in && iy < p.H && ix < p.W;
+                }
+                if (in) {
+                    v = ld128(sp + (int64_t)(a_pix[i] + iy * p.W + ix) * ld + cc);
+                    if (p.in_scale) {
+                        const int so = a_img[i] * p.cin + kc;
+                        v = affine16<T>(v, p.in_scale + so, p.in_shift + so);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+        const int k_elem = tap * p.cin + kc;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int row = rbase + 32 * i;
+            const int n = n0 + row;
+            u128 v = zero128();
+            if (row < BN && n < p.coutT && tap_ok) v = ld128(wgt + (int64_t)n * p.K + k_elem);
+            rb[i] = v;
+        }
+    };
+    auto advance_k = [&]() {
+        kc += BK;
+        while (kc >= p.cin) {
+            kc -= p.cin;
+            ++tap;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = rbase + 32 * i;
+            if (row < BM) st128(sA(buf) + row * 128 + ((j ^ (row & 7)) << 4), ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int row = rbase + 32 * i;
+            if (row < BN) st128(sB(buf) + row * 128 + ((j ^ (row & 7)) << 4), rb[i]);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
+    const int a_row0 = wm * (TM * 16) + l15, b_row0 = wn * (TN * 16) + l15;
+
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            advance_k();
+            load_tiles();
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int phys = ((sub * 4 + q) ^ l7) << 4;
+            u128 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = ld128(sA(buf) + (a_row0 + a * 16) * 128 + phys);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = ld128(sB(buf) + (b_row0 + b * 16) * 128 + phys);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------
+    float* stage = reinterpret_cast<float*>(smem);
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+#pragma unroll
+    for (int pass = 0; pass < TM; ++pass) {
+        if (pass > 0) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int colb = wn * (TN * 16) + b * 16;
+            const int n = n0 + colb + l15;
+            const int co = (p.phases > 1) ? n % p.cout : n;
+            const float bv = (p.bias && n < p.coutT) ? p.bias[co] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[pass][b][r] + bv;
+                if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
+                else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
+                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = v * ga;
+            }
+        }
+        __syncthreads();
+        if (p.out_layout == VT_OUT_NHWC) {
+            constexpr int CV = BN / 8;
+            for (int idx = tid; idx < SROWS * CV; idx += 256) {
+                const int row_l = idx / CV, cv = idx - row_l * CV;
+                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int n = n0 + cv * 8;
+                if (m >= p.M || n >= p.coutT) continue;
+                float f[8];
+                {
+                    const u128 lo = ld128(stage + row_l * SLD + cv * 8);
+                    const u128 hi = ld128(stage + row_l * SLD + cv * 8 + 4);
+                    unpack16<float>(lo, f);
+                    unpack16<float>(hi, f + 4);
+                }
+                int64_t opix = m;
+                int co = n;
+                if (p.phases > 1) {
+                    const int ph = n / p.cout;
+                    co = n - ph * p.cout;
+                    const int img = m / HoWo;
+                    const int rem = m - img * HoWo;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    opix = ((int64_t)img * (2 * p.Ho) + 2 * oy + (ph >> 1)) * (2 * p.Wo) + 2 * ox + (ph & 1);
+                }
+                const int lim = (p.phases > 1) ? p.cout : p.coutT;
+                const int nvalid = (lim - co) < 8 ? (lim - co) : 8;
+                if (p.out_f32) {
+                    float* o = (float*)p.out + opix * p.ld_out + co;
+                    const float* rs = p.resid ? (const float*)p.resid + opix * p.ld_res + co : nullptr;
+                    if (p.vec_store && nvalid == 8) {
+                        if (rs) {
+                            float g[8];
+                            unpack16<float>(ld128(rs), g);
+                            unpack16<float>(ld128(rs + 4), g + 4);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
+                        }
+                        st128(o, pack16<float>(f));
+                        st128(o + 4, pack16<float>(f + 4));
+                    } else {
+                        for (int i = 0; i < nvalid; ++i) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
+                    }
+                } else {
+                    bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
+                    const bf16_t* rs = p.resid ? (const bf16_t*)p.resid + opix * p.ld_res + co : nullptr;
+                    if (p.vec_store && nvalid == 8) {
+                        if (rs) {
+                            float g[8];
+                            unpack16<bf16_t>(ld128(rs), g);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
+                        }
+                        st128(o, pack16<bf16_t>(f));
+                    } else {
+                        for (int i = 0; i < nvalid; ++i)
+                            o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
+                    }
+                }
+            }
+        } else {
+            // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
+            float* o = (float*)p.out;
+            const float* rs = (const float*)p.resid;
+            for (int idx = tid; idx < SROWS * BN; idx += 256) {
+                const int col = idx / SROWS, row_l = idx - col * SROWS;
+                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int n = n0 + col;
+                if (m >= p.M || n >= p.coutT) continue;
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int64_t off = ((int64_t)img * p.cout + n) * HoWo + rem;
+                float v = stage[row_l * SLD + col];
+                if (rs) v += p.beta * rs[off];
+                o[off] = v;
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const ConvArgs& a, vt_stream stream) {
+    ConvArgs args = a;
+    args.tiles_n = vt_cdiv(a.coutT, BN);
+    const int64_t tiles = (int64_t)vt_cdiv(a.M, BM) * args.tiles_n;
+    if (tiles >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;
+    VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
+    return vt_check_launch("vt_conv2d");
+}
+
+template <typename T>
+int dispatch(const ConvArgs& a, int hint, vt_stream stream) {
+    int bm = 0, bn = 0;
+    if (hint > 0) {
+        bm = hint / 1000;
+        bn = hint % 1000;
+    } else {
+        bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
+        bm = 128;
+        // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
+        auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(a.M, m) * vt_cdiv(a.coutT, n); };
+        if (bn == 128 && tiles(128, 128) < 512) bn = 64;
+        if (tiles(bm, bn) < 512) bm = 64;
+        if (bn == 64 && tiles(bm, bn) < 256 && bm == 64) bm = 32;
+        if (bn == 16 || bn == 32) bm = 128;
+    }
+#define VT_CFG(M_, N_, WM_, WN_) \
+    if (bm == M_ && bn == N_) return launch_cfg<T, M_, N_, WM_, WN_>(a, stream);
+    VT_CFG(128, 128, 2, 2)
+    VT_CFG(128, 64, 2, 2)
+    VT_CFG(128, 32, 4, 1)
+    VT_CFG(128, 16, 4, 1)
+    VT_CFG(64, 64, 2, 2)
+    VT_CFG(64, 128, 2, 2)
+    VT_CFG(32, 64, 2, 2)
+#undef VT_CFG
+    vt_set_error("vt_conv2d: no compiled tile %dx%d", bm, bn);
+    return VT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
+    VT_REQUIRE(d, "vt_conv2d: null descriptor");
+    VT_REQUIRE(d->src0 && d->weight && d->out, "vt_conv2d: null tensor");
+    VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv2d: dtype must be fp32 or bf16");
+    VT_REQUIRE(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 >= 0 && d->c1 % 8 == 0,
+               "vt_conv2d: channel counts must be multiples of 8 (got %d,%d)", d->c0, d->c1);
+    VT_REQUIRE(d->c1 == 0 || d->src1, "vt_conv2d: c1 > 0 but src1 is null");
+    VT_REQUIRE(d->ld0 >= d->c0 && (d->c1 == 0 || d->ld1 >= d->c1), "vt_conv2d: pixel stride < channels");
+    const int esz = d->dtype == VT_F32 ? 4 : 2;
+    VT_REQUIRE(((uintptr_t)d->src0 % 16 == 0) && ((int64_t)d->ld0 * esz % 16 == 0) &&
+                   ((uintptr_t)d->weight % 16 == 0),
+               "vt_conv2d: src0/weight must be 16-byte aligned with 16-byte pixel stride");
+    VT_REQUIRE(d->c1 == 0 || (((uintptr_t)d->src1 % 16 == 0) && ((int64_t)d->ld1 * esz % 16 == 0)),
+               "vt_conv2d: src1 must be 16-byte aligned with 16-byte pixel stride");
+    VT_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->out_h > 0 && d->out_w > 0, "vt_conv2d: bad sizes");
+    VT_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->cout > 0, "vt_conv2d: bad conv params");
+    VT_REQUIRE(d->phases == 1 || d->phases == 4, "vt_conv2d: phases must be 1 or 4");
+    VT_REQUIRE(d->phases == 1 || (d->cout % 8 == 0 && d->out_layout == VT_OUT_NHWC && !d->transposed),
+               "vt_conv2d: polyphase form needs cout %% 8 == 0 and NHWC output");
+    VT_REQUIRE(d->out_layout == VT_OUT_NHWC || d->out_dtype == VT_F32, "vt_conv2d: NCHW output is fp32 only");
+    VT_REQUIRE(d->out_dtype == VT_F32 || d->out_dtype == VT_BF16, "vt_conv2d: bad out dtype");
+    VT_REQUIRE((int64_t)d->n * d->h * d->w < ((int64_t)1 << 31) &&
+                   (int64_t)d->n * d->out_h * d->out_w * (d->phases == 4 ? 4 : 1) < ((int64_t)1 << 31),
+               "vt_conv2d: tensor too large for 32-bit pixel indices");
+
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = d->src0;
+    a.src1 = d->src1;
+    a.wgt = d->weight;
+    a.bias = d->bias;
+    a.alpha_dev = d->alpha_dev;
+    a.in_scale = d->in_scale;
+    a.in_shift = d->in_shift;
+    a.resid = d->resid;
+    a.out = d->out;
+    a.c0 = d->c0;
+    a.c1 = d->c1;
+    a.ld0 = d->ld0;
+    a.ld1 = d->ld1;
+    a.cin = d->c0 + d->c1;
+    a.N = d->n;
+    a.H = d->h;
+    a.W = d->w;
+    a.Ho = d->out_h;
+    a.Wo = d->out_w;
+    a.cout = d->cout;
+    a.coutT = d->cout * d->phases;
+    a.taps = d->kh * d->kw;
+    a.kw = d->kw;
+    a.K = a.taps * a.cin;
+    a.stride = d->stride;
+    a.pad = d->pad;
+    a.dil = d->dil;
+    a.transposed = d->transposed;
+    a.phases = d->phases;
+    a.act = d->act;
+    a.slope = d->slope;
+    a.gain_alpha = d->gain * d->alpha;
+    a.beta = d->beta;
+    a.ld_res = d->ld_res;
+    a.ld_out = d->ld_out;
+    a.out_layout = d->out_layout;
+    a.out_f32 = d->out_dtype == VT_F32;
+    a.M = d->n * d->out_h * d->out_w;
+    const int osz = a.out_f32 ? 4 : 2;
+    a.vec_store = (d->out_layout == VT_OUT_NHWC) && ((uintptr_t)d->out % 16 == 0) &&
+                  ((int64_t)d->ld_out * osz % 16 == 0) && (d->cout % 8 == 0) &&
+                  (!d->resid || (((uintptr_t)d->resid % 16 == 0) && ((int64_t)d->ld_res * osz % 16 == 0)));
+    if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, stream);
+    return dispatch<float>(a, d->tile_hint, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA lane-map self test: one wavefront computes C(16x16) = A(16xKK) * B(16xKK)^T with
+// the same fragment addressing as the conv kernel (KK = 32 bf16 / 16 fp32 = one sub-step).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) mfma_selftest_kernel(float* c, const T* a, const T* b) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, q = lane >> 4, l15 = lane & 15;
+    const u128 fa = ld128(a + l15 * (4 * VEC) + q * VEC);
+    const u128 fb = ld128(b + l15 * (4 * VEC) + q * VEC);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    Mma<T>::run(acc, fa, fb);
+    for (int r = 0; r < 4; ++r) c[(q * 4 + r) * 16 + l15] = acc[r];
+}
+
+extern "C" int vt_mfma_selftest(float* c, const void* a, const void* b, int dtype, vt_stream stream) {
+    VT_REQUIRE(c && a && b, "vt_mfma_selftest: null tensor");
+    if (dtype == VT_BF16) {
+        auto k = mfma_selftest_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(1), dim3(64), stream, c, (const bf16_t*)a, (const bf16_t*)b);
+    } else if (dtype == VT_F32) {
+        auto k = mfma_selftest_kernel<float>;
+        VT_LAUNCH(k, dim3(1), dim3(64), stream, c, (const float*)a, (const float*)b);
+    } else {
+        vt_set_error("vt_mfma_selftest: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_mfma_selftest");
+}

@@ -1,0 +1,401 @@
+// Normalisation and fusion glue on NHWC activations (gfx950), all HBM-streaming:
+//   vt_instnorm_stats  nn.InstanceNorm2d statistics folded with the AdaIN affine
+//                      (model/dualstylegan.py:6-21) into per-(n,c) scale/shift
+//   vt_affine_apply    x*scale+shift, optionally on cat[x, |x-other|] (model/vtoonify.py:125)
+//   vt_fusion_pack     [skip | f_E * m_E] operand of fusion_out.conv / fusion_skip
+//                      (model/vtoonify.py:127, 259-262)
+//   vt_nchw_to_nhwc / vt_nhwc_to_nchw   layout change at the model boundary
+//
+// Statistics are deterministic (no float atomics): every workgroup reduces a chunk of
+// pixels to per-channel {x0, sum(x-x0), sum((x-x0)^2)} with the chunk's first pixel as the
+// shift x0 (kills the E[x^2]-E[x]^2 cancellation), and a second kernel merges the chunks
+// in fixed order with Chan's parallel-variance update in fp64.
+#include "vt_common.hpp"
+
+namespace {
+
+constexpr float IN_EPS = 1e-5f;  // nn.InstanceNorm2d default (dualstylegan.py:10)
+
+struct StatRec {
+    float x0, s1, s2;
+};
+
+// chunk geometry shared by host and device
+__host__ __device__ inline int stat_chunk_pixels(int n, int hw) {
+    // aim for >= ~512 workgroups, 64..1024 pixels each
+    int64_t px = ((int64_t)n * hw) / 512;
+    if (px < 64) px = 64;
+    if (px > 1024) px = 1024;
+    return (int)px;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int ld_x,
+                        const T* __restrict__ other, int ld_o, int hw, int c, int chunk_px,
+                        int chunks) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float red[256 * VEC * 2];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x % chunks, img = blockIdx.x / chunks;
+    const int p_lo = chunk * chunk_px;
+    const int p_hi = (p_lo + chunk_px < hw) ? p_lo + chunk_px : hw;
+    const int cvn = c / VEC;
+    const int cpar = cvn < 256 ? cvn : 256;  // channel-vectors handled in parallel
+    const int rows = 256 / cpar;             // pixel rows handled in parallel
+    const int cv0 = tid % cpar, prow = tid / cpar;
+    const bool active = prow < rows;
+    const int halves = other ? 2 : 1;
+    const int ctot = c * halves;
+    const T* xb = x + (int64_t)img * hw * ld_x;
+    const T* ob = other ? other + (int64_t)img * hw * ld_o : nullptr;
+
+    for (int cbase = 0; cbase < cvn; cbase += cpar) {
+        const int cv = cbase + cv0;
+        const bool on = active && cv < cvn;
+        for (int half = 0; half < halves; ++half) {
+            float x0[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) x0[i] = s1[i] = s2[i] = 0.0f;
+            if (on) {
+                {
+                    float f[VEC];
+                    unpack16<T>(ld128(xb + (int64_t)p_lo * ld_x + cv * VEC), f);
+                    if (half == 1) {
+                        float g[VEC];
+                        unpack16<T>(ld128(ob + (int64_t)p_lo * ld_o + cv * VEC), g);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) f[i] = fabsf(f[i] - g[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) x0[i] = f[i];
+                }
+                for (int px = p_lo + prow; px < p_hi; px += rows) {
+                    float f[VEC];
+                    unpack16<T>(ld128(xb + (int64_t)px * ld_x + cv * VEC), f);
+                    if (half == 1) {
+                        float g[VEC];
+                        unpack16<T>(ld128(ob + (int64_t)px * ld_o + cv * VEC), g);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) f[i] = fabsf(f[i] - g[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float d = f[i] - x0[i];
+                        s1[i] += d;
+                        s2[i] += d * d;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                red[(tid * VEC + i) * 2 + 0] = s1[i];
+                red[(tid * VEC + i) * 2 + 1] = s2[i];
+            }
+            __syncthreads();
+            // thread (prow == 0) of each channel-vector folds the pixel rows in order
+            if (on && prow == 0) {
+                for (int i = 0; i < VEC; ++i) {
+                    float a1 = 0.0f, a2 = 0.0f;
+                    for (int r = 0; r < rows; ++r) {
+                        const int t = r * cpar + cv0;
+                        a1 += red[(t * VEC + i) * 2 + 0];
+                        a2 += red[(t * VEC + i) * 2 + 1];
+                    }
+                    StatRec rec;
+                    rec.x0 = x0[i];
+                    rec.s1 = a1;
+                    rec.s2 = a2;
+                    part[((int64_t)img * chunks + chunk) * ctot + half * c + cv * VEC + i] = rec;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+instnorm_finalize_kernel(float* __restrict__ scale, float* __restrict__ shift,
+                         const StatRec* __restrict__ part, int n, int hw, int ctot, int chunk_px,
+                         int chunks, const float* __restrict__ style_gb, int ld_gb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * ctot) return;
+    const int img = idx / ctot, ch = idx - img * ctot;
+    double cnt = 0.0, mean = 0.0, m2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const StatRec r = part[((int64_t)img * chunks + k) * ctot + ch];
+        int npx = hw - k * chunk_px;
+        if (npx > chunk_px) npx = chunk_px;
+        const double nb = (double)npx;
+        const double mb = (double)r.x0 + (double)r.s1 / nb;
+        const double m2b = (double)r.s2 - (double)r.s1 * (double)r.s1 / nb;
+        const double delta = mb - mean;
+        const double tot = cnt + nb;
+        mean += delta * nb / tot;
+        m2 += m2b + delta * delta * cnt * nb / tot;
+        cnt = tot;
+    }
+    double var = m2 / cnt;  // biased, as F.instance_norm
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+    float gamma = 1.0f, beta = 0.0f;
+    if (style_gb) {
+        gamma = style_gb[(int64_t)img * ld_gb + ch];
+        beta = style_gb[(int64_t)img * ld_gb + ctot + ch];
+    }
+    scale[idx] = gamma * rstd;
+    shift[idx] = beta - gamma * rstd * (float)mean;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+affine_apply_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
+                    const T* __restrict__ other, int ld_o, const float* __restrict__ scale,
+                    const float* __restrict__ shift, int n, int hw, int c) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cvn = c / VEC;
+    const int halves = other ? 2 : 1;
+    const int ctot = c * halves;
+    const int64_t total = (int64_t)n * hw * cvn * halves;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int cvh = (int)(i % (cvn * halves));
+        const int64_t pix = i / (cvn * halves);  // global pixel index n*hw + p
+        const int half = cvh / cvn, cv = cvh - half * cvn;
+        const int img = (int)(pix / hw);
+        float f[VEC];
+        unpack16<T>(ld128(x + pix * ld_x + cv * VEC), f);
+        if (half == 1) {
+            float g[VEC];
+            unpack16<T>(ld128(other + pix * ld_o + cv * VEC), g);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) f[k] = fabsf(f[k] - g[k]);
+        }
+        const int so = img * ctot + half * c + cv * VEC;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] = f[k] * scale[so + k] + shift[so + k];
+        st128(out + pix * ld_out + half * c + cv * VEC, pack16<T>(f));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+fusion_pack_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ f_e, int ld_e,
+                   const float* __restrict__ mask, const float* __restrict__ skip, int n, int hw,
+                   int c) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cvn = c / VEC;
+    const int hv = 8 / VEC;  // header vectors: 8 channels [skip(3) | 0 x5]
+    const int per_px = cvn + hv;
+    const int64_t total = (int64_t)n * hw * per_px;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int v = (int)(i % per_px);
+        const int64_t pix = i / per_px;
+        T* o = out + pix * ld_out;
+        if (v < hv) {
+            const int img = (int)(pix / hw);
+            const int p = (int)(pix - (int64_t)img * hw);
+            float f[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int ch = v * VEC + k;
+                f[k] = (ch < 3) ? skip[((int64_t)img * 3 + ch) * hw + p] : 0.0f;
+            }
+            st128(o + v * VEC, pack16<T>(f));
+        } else {
+            const int cv = v - hv;
+            const float m = mask ? mask[pix] : 1.0f;
+            float f[VEC];
+            unpack16<T>(ld128(f_e + pix * ld_e + cv * VEC), f);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) f[k] *= m;
+            st128(o + 8 + cv * VEC, pack16<T>(f));
+        }
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(TO* __restrict__ out, int ld_out, const TI* __restrict__ in, int n, int c,
+                    int hw, int cpad) {
+    // one thread per (pixel, group of 8 channels); lanes walk pixels so the strided
+    // plane reads are coalesced
+    const int groups = cpad / 8;
+    const int64_t total = (int64_t)n * groups * hw;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int p = (int)(i % hw);
+        const int64_t t = i / hw;
+        const int g = (int)(t % groups);
+        const int img = (int)(t / groups);
+        TO* o = out + ((int64_t)img * hw + p) * ld_out + g * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = g * 8 + k;
+            const float v = ch < c ? to_f32(in[((int64_t)img * c + ch) * hw + p]) : 0.0f;
+            o[k] = from_f32<TO>(v);
+        }
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(TO* __restrict__ out, const TI* __restrict__ in, int ld_in, int n, int c,
+                    int hw) {
+    const int64_t total = (int64_t)n * c * hw;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int p = (int)(i % hw);
+        const int64_t t = i / hw;
+        const int ch = (int)(t % c);
+        const int img = (int)(t / c);
+        out[i] = from_f32<TO>(to_f32(in[((int64_t)img * hw + p) * ld_in + ch]));
+    }
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int64_t vt_instnorm_ws_bytes(int n, int hw, int c_total) {
+    if (n <= 0 || hw <= 0 || c_total <= 0) return 0;
+    const int cpx = stat_chunk_pixels(n, hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    return (int64_t)n * chunks * c_total * (int64_t)sizeof(StatRec);
+}
+
+extern "C" int vt_instnorm_stats(float* scale, float* shift, const void* x, int ld_x,
+                                 const void* absdiff_other, int ld_other, int n, int hw, int c,
+                                 const float* style_gb, int ld_gb, void* partials, int dtype,
+                                 vt_stream stream) {
+    VT_REQUIRE(scale && shift && x && partials, "vt_instnorm_stats: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_instnorm_stats: c must be a positive multiple of 8");
+    VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_stats: dtype");
+    const int cpx = stat_chunk_pixels(n, hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    const int ctot = absdiff_other ? 2 * c : c;
+    dim3 grid((unsigned)(n * chunks)), block(256);
+    if (dtype == VT_F32) {
+        auto k = instnorm_partial_kernel<float>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const float*)x, ld_x,
+                  (const float*)absdiff_other, ld_other, hw, c, cpx, chunks);
+    } else {
+        auto k = instnorm_partial_kernel<bf16_t>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const bf16_t*)x, ld_x,
+                  (const bf16_t*)absdiff_other, ld_other, hw, c, cpx, chunks);
+    }
+    int rc = vt_check_launch("vt_instnorm_stats(partial)");
+    if (rc) return rc;
+    VT_LAUNCH(instnorm_finalize_kernel, dim3((unsigned)((n * ctot + 255) / 256)), dim3(256), stream,
+              scale, shift, (const StatRec*)partials, n, hw, ctot, cpx, chunks, style_gb, ld_gb);
+    return vt_check_launch("vt_instnorm_stats(finalize)");
+}
+
+extern "C" int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
+                               const void* absdiff_other, int ld_other, const float* scale,
+                               const float* shift, int n, int hw, int c, int dtype,
+                               vt_stream stream) {
+    VT_REQUIRE(out && x && scale && shift, "vt_affine_apply: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_affine_apply: c must be a positive multiple of 8");
+    const int halves = absdiff_other ? 2 : 1;
+    if (dtype == VT_F32) {
+        const int64_t total = (int64_t)n * hw * (c / 4) * halves;
+        auto k = affine_apply_kernel<float>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, (const float*)x, ld_x,
+                  (const float*)absdiff_other, ld_other, scale, shift, n, hw, c);
+    } else if (dtype == VT_BF16) {
+        const int64_t total = (int64_t)n * hw * (c / 8) * halves;
+        auto k = affine_apply_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (bf16_t*)out, ld_out, (const bf16_t*)x, ld_x,
+                  (const bf16_t*)absdiff_other, ld_other, scale, shift, n, hw, c);
+    } else {
+        vt_set_error("vt_affine_apply: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_affine_apply");
+}
+
+extern "C" int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float* mask,
+                              const float* skip, int n, int hw, int c, int dtype, vt_stream stream) {
+    VT_REQUIRE(out && f_e && skip, "vt_fusion_pack: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ld_out >= c + 8, "vt_fusion_pack: bad sizes");
+    if (dtype == VT_F32) {
+        const int64_t total = (int64_t)n * hw * (c / 4 + 2);
+        auto k = fusion_pack_kernel<float>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, (const float*)f_e, ld_e,
+                  mask, skip, n, hw, c);
+    } else if (dtype == VT_BF16) {
+        const int64_t total = (int64_t)n * hw * (c / 8 + 1);
+        auto k = fusion_pack_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (bf16_t*)out, ld_out, (const bf16_t*)f_e, ld_e,
+                  mask, skip, n, hw, c);
+    } else {
+        vt_set_error("vt_fusion_pack: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_fusion_pack");
+}
+
+template <typename TI>
+static int nchw_to_nhwc_out(void* out, int ld_out, const TI* in, int n, int c, int hw, int out_dtype,
+                            vt_stream stream) {
+    const int cpad = (c + 7) / 8 * 8;
+    const int64_t total = (int64_t)n * (cpad / 8) * hw;
+    if (out_dtype == VT_F32) {
+        auto k = nchw_to_nhwc_kernel<TI, float>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, in, n, c, hw, cpad);
+    } else if (out_dtype == VT_BF16) {
+        auto k = nchw_to_nhwc_kernel<TI, bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (bf16_t*)out, ld_out, in, n, c, hw, cpad);
+    } else {
+        vt_set_error("vt_nchw_to_nhwc: out dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_nchw_to_nhwc");
+}
+
+extern "C" int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,
+                               int in_dtype, int out_dtype, vt_stream stream) {
+    VT_REQUIRE(out && in && n > 0 && c > 0 && hw > 0, "vt_nchw_to_nhwc: bad arguments");
+    VT_REQUIRE(ld_out >= (c + 7) / 8 * 8, "vt_nchw_to_nhwc: ld_out must cover c rounded up to 8");
+    if (in_dtype == VT_F32) return nchw_to_nhwc_out<float>(out, ld_out, (const float*)in, n, c, hw, out_dtype, stream);
+    if (in_dtype == VT_BF16) return nchw_to_nhwc_out<bf16_t>(out, ld_out, (const bf16_t*)in, n, c, hw, out_dtype, stream);
+    if (in_dtype == VT_F16) return nchw_to_nhwc_out<f16_t>(out, ld_out, (const f16_t*)in, n, c, hw, out_dtype, stream);
+    vt_set_error("vt_nchw_to_nhwc: in dtype");
+    return VT_ERR_UNSUPPORTED;
+}
+
+template <typename TI>
+static int nhwc_to_nchw_out(void* out, const TI* in, int ld_in, int n, int c, int hw, int out_dtype,
+                            vt_stream stream) {
+    const int64_t total = (int64_t)n * c * hw;
+    if (out_dtype == VT_F32) {
+        auto k = nhwc_to_nchw_kernel<TI, float>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, in, ld_in, n, c, hw);
+    } else if (out_dtype == VT_BF16) {
+        auto k = nhwc_to_nchw_kernel<TI, bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (bf16_t*)out, in, ld_in, n, c, hw);
+    } else if (out_dtype == VT_F16) {
+        auto k = nhwc_to_nchw_kernel<TI, f16_t>;
+        VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (f16_t*)out, in, ld_in, n, c, hw);
+    } else {
+        vt_set_error("vt_nhwc_to_nchw: out dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_nhwc_to_nchw");
+}
+
+extern "C" int vt_nhwc_to_nchw(void* out, const void* in, int ld_in, int n, int c, int hw,
+                               int in_dtype, int out_dtype, vt_stream stream) {
+    VT_REQUIRE(out && in && n > 0 && c > 0 && hw > 0 && ld_in >= c, "vt_nhwc_to_nchw: bad arguments");
+    if (in_dtype == VT_F32) return nhwc_to_nchw_out<float>(out, (const float*)in, ld_in, n, c, hw, out_dtype, stream);
+    if (in_dtype == VT_BF16) return nhwc_to_nchw_out<bf16_t>(out, (const bf16_t*)in, ld_in, n, c, hw, out_dtype, stream);
+    vt_set_error("vt_nhwc_to_nchw: in dtype");
+    return VT_ERR_UNSUPPORTED;
+}

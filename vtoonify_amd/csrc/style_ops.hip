@@ -1,0 +1,223 @@
+// Style path of the synthesis network on gfx950 (frame-invariant per (style, d_s)):
+//   vt_linear          EqualLinear / nn.Linear            model/stylegan/model.py:152-162
+//   vt_pixel_norm      PixelNorm                          model/stylegan/model.py:17-18
+//   vt_modulate_weight ModulatedConv2d modulate + demod   model/stylegan/model.py:259-267
+//                      (+ polyphase fold of conv_transpose2d + Blur, model.py:273-286)
+//   vt_pack_conv_weight  plain conv weights -> implicit-GEMM layout
+//
+// All reductions (dot products, sum of squares over cin*k*k <= 4608 elements) are done
+// by ONE 64-lane wavefront per output with xor-shuffle butterflies -- no LDS, no
+// atomics, deterministic.
+#include "vt_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// y[r,o] = act(dot(x[r,:], W[o,:]) * w_scale + b[o] * b_scale)
+// The reference scales the weight matrix (W*scale) before the GEMV; scaling the dot
+// product instead differs only by fp32 reassociation.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+linear_kernel(float* __restrict__ y, int ld_y, const float* __restrict__ x, int ld_x,
+              const float* __restrict__ W, const float* __restrict__ b, int rows, int in_dim,
+              int out_dim, float w_scale, float b_scale, int act, float slope, float gain) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t total = (int64_t)rows * out_dim;
+    // no early return before the shuffles: clamp and mask the store instead
+    const int64_t wi = wave < total ? wave : total - 1;
+    const int r = (int)(wi / out_dim), o = (int)(wi % out_dim);
+    const float* xr = x + (int64_t)r * ld_x;
+    const float* wr = W + (int64_t)o * in_dim;
+    float acc = 0.0f;
+    for (int i = lane; i < in_dim; i += 64) acc += xr[i] * wr[i];
+    acc = wave_sum(acc);
+    if (lane == 0 && wave < total) {
+        float v = acc * w_scale;
+        if (b) v += b[o] * b_scale;
+        if (act == VT_ACT_LRELU) v = ((v > 0.0f) ? v : v * slope) * gain;
+        y[(int64_t)r * ld_y + o] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pixel_norm_kernel(float* __restrict__ y, const float* __restrict__ x, int rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = wave < rows ? wave : rows - 1;
+    const float* xr = x + (int64_t)r * dim;
+    float ss = 0.0f;
+    for (int i = lane; i < dim; i += 64) ss += xr[i] * xr[i];
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)dim + 1e-8f);
+    if (wave < rows)
+        for (int i = lane; i < dim; i += 64) y[(int64_t)r * dim + i] = xr[i] * inv;
+}
+
+// ---------------------------------------------------------------------------------
+// Modulated conv weight.  One wavefront per output channel `co`.
+//   pass 1: sumsq over (ci, tap) of (scale * w * s[ci])^2  -> demod
+//   pass 2: write packed [co][tap][ci]                      (fir == nullptr)
+//        or the four 3x3 polyphase filters of convT(stride 2) followed by the 4x4 blur:
+//           Weff[p=(py,px)][co][ky,kx][ci] =
+//               sum_{a,b} w'[co,ci,a,b] * K[4 - 2ky - a + py][4 - 2kx - b + px]
+//           (K indices outside 0..3 contribute 0), packed [p*cout + co][ky*3+kx][ci].
+//     Derivation: DESIGN.md "Up-sampling StyledConv as one polyphase GEMM".
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+modulate_weight_kernel(T* __restrict__ out, const float* __restrict__ w, const float* __restrict__ s,
+                       int cout, int cin, int k, float scale, int demodulate,
+                       const float* __restrict__ fir) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int co = wave < cout ? wave : cout - 1;
+    const bool live = wave < cout;
+    const int taps = k * k;
+    const int n = cin * taps;
+    const float* wc = w + (int64_t)co * n;  // [ci][a][b]
+    float demod = 1.0f;
+    if (demodulate) {
+        float ss = 0.0f;
+        for (int i = lane; i < n; i += 64) {
+            const float v = scale * wc[i] * s[i / taps];
+            ss += v * v;
+        }
+        ss = wave_sum(ss);
+        demod = rsqrtf(ss + 1e-8f);
+    }
+    if (!live) return;
+    if (fir == nullptr) {
+        T* oc = out + (int64_t)co * n;  // [tap][ci]
+        for (int i = lane; i < n; i += 64) {
+            const int tap = i / cin, ci = i - tap * cin;
+            const float v = scale * wc[ci * taps + tap] * s[ci] * demod;
+            oc[i] = from_f32<T>(v);
+        }
+    } else {
+        // k == 3, fir 4x4
+        float K[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) K[i] = fir[i];
+        for (int ci = lane; ci < cin; ci += 64) {
+            float wm[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wm[t] = scale * wc[ci * 9 + t] * s[ci] * demod;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int py = p >> 1, px = p & 1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const int u = 4 - 2 * ky - a + py;
+                            if (u < 0 || u > 3) continue;
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                const int v = 4 - 2 * kx - b + px;
+                                if (v < 0 || v > 3) continue;
+                                acc += wm[a * 3 + b] * K[u * 4 + v];
+                            }
+                        }
+                        out[((int64_t)(p * cout + co) * 9 + (ky * 3 + kx)) * cin + ci] = from_f32<T>(acc);
+                    }
+            }
+        }
+    }
+}
+
+// out[co][tap][cd] = scale * w[co][map[cd]][tap]   (or 0 when map[cd] < 0)
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(T* __restrict__ out, const float* __restrict__ w, int cout, int cin_src, int kh,
+                   int kw, int cin_dst, const int32_t* __restrict__ chan_map, float scale,
+                   int src_transposed) {
+    const int taps = kh * kw;
+    const int64_t total = (int64_t)cout * taps * cin_dst;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int cd = (int)(i % cin_dst);
+        const int64_t t = i / cin_dst;
+        const int tap = (int)(t % taps);
+        const int co = (int)(t / taps);
+        const int cs = chan_map ? chan_map[cd] : (cd < cin_src ? cd : -1);
+        float v = 0.0f;
+        if (cs >= 0) {
+            if (!src_transposed) {
+                v = w[((int64_t)co * cin_src + cs) * taps + tap];
+            } else {
+                // source (cin, cout, kh, kw); the gather form of conv_transpose2d visits
+                // tap (ky,kx) at input offset -(ky,kx)*dil, so taps keep their index.
+                v = w[((int64_t)cs * cout + co) * taps + tap];
+            }
+        }
+        out[i] = from_f32<T>(v * scale);
+    }
+}
+
+}  // namespace
+
+extern "C" int vt_linear(float* y, int ld_y, const float* x, int ld_x, const float* W,
+                         const float* b, int rows, int in_dim, int out_dim, float w_scale,
+                         float b_scale, int act, float slope, float gain, vt_stream stream) {
+    VT_REQUIRE(y && x && W, "vt_linear: null tensor");
+    VT_REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0, "vt_linear: bad sizes");
+    VT_REQUIRE(act == VT_ACT_NONE || act == VT_ACT_LRELU, "vt_linear: unsupported act %d", act);
+    if (rows == 0) return VT_OK;
+    const int64_t waves = (int64_t)rows * out_dim;
+    VT_LAUNCH(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), stream, y, ld_y, x, ld_x,
+              W, b, rows, in_dim, out_dim, w_scale, b_scale, act, slope, gain);
+    return vt_check_launch("vt_linear");
+}
+
+extern "C" int vt_pixel_norm(float* y, const float* x, int rows, int dim, vt_stream stream) {
+    VT_REQUIRE(y && x && rows >= 0 && dim > 0, "vt_pixel_norm: bad arguments");
+    if (rows == 0) return VT_OK;
+    VT_LAUNCH(pixel_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, x, rows, dim);
+    return vt_check_launch("vt_pixel_norm");
+}
+
+extern "C" int vt_modulate_weight(void* out, const float* weight, const float* s, int cout, int cin,
+                                  int k, float scale, int demodulate, const float* fir,
+                                  int out_dtype, vt_stream stream) {
+    VT_REQUIRE(out && weight && s, "vt_modulate_weight: null tensor");
+    VT_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3), "vt_modulate_weight: bad shape");
+    VT_REQUIRE(!fir || k == 3, "vt_modulate_weight: polyphase fold needs a 3x3 kernel");
+    dim3 grid((unsigned)((cout + 3) / 4)), block(256);
+    if (out_dtype == VT_F32) {
+        auto kf = modulate_weight_kernel<float>;
+        VT_LAUNCH(kf, grid, block, stream, (float*)out, weight, s, cout, cin, k, scale, demodulate, fir);
+    } else if (out_dtype == VT_BF16) {
+        auto kf = modulate_weight_kernel<bf16_t>;
+        VT_LAUNCH(kf, grid, block, stream, (bf16_t*)out, weight, s, cout, cin, k, scale, demodulate, fir);
+    } else {
+        vt_set_error("vt_modulate_weight: unsupported dtype %d", out_dtype);
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_modulate_weight");
+}
+
+extern "C" int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_src, int kh, int kw,
+                                   int cin_dst, const int32_t* chan_map, float scale,
+                                   int src_transposed, int out_dtype, vt_stream stream) {
+    VT_REQUIRE(out && w, "vt_pack_conv_weight: null tensor");
+    VT_REQUIRE(cout > 0 && cin_src > 0 && cin_dst > 0 && kh > 0 && kw > 0, "vt_pack_conv_weight: bad shape");
+    const int64_t total = (int64_t)cout * kh * kw * cin_dst;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    if (out_dtype == VT_F32) {
+        auto kf = pack_weight_kernel<float>;
+        VT_LAUNCH(kf, grid, block, stream, (float*)out, w, cout, cin_src, kh, kw, cin_dst, chan_map, scale, src_transposed);
+    } else if (out_dtype == VT_BF16) {
+        auto kf = pack_weight_kernel<bf16_t>;
+        VT_LAUNCH(kf, grid, block, stream, (bf16_t*)out, w, cout, cin_src, kh, kw, cin_dst, chan_map, scale, src_transposed);
+    } else {
+        vt_set_error("vt_pack_conv_weight: unsupported dtype %d", out_dtype);
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_pack_conv_weight");
+}

@@ -1,0 +1,182 @@
+// Shared device helpers for the gfx950 kernels of libvtoonify_amd.so.
+//
+// Two build modes:
+//   (default)  hipcc --offload-arch=gfx950        the product
+//   -DVT_EMU   host clang++ with tests/emu/hip_emu.hpp force-included: the same kernel
+//              sources run as coroutines on the CPU so index arithmetic, LDS tiling and
+//              epilogues can be debugged in the GPU-less authoring container.  The
+//              emulator is test infrastructure only; the Python loader never picks it.
+#pragma once
+
+#ifndef VT_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vtoonify_amd.h"
+
+// ---------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------
+void vt_set_error(const char* fmt, ...);
+int vt_check_launch(const char* what);
+
+#define VT_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            vt_set_error(__VA_ARGS__);   \
+            return VT_ERR_ARG;           \
+        }                                \
+    } while (0)
+
+#ifdef VT_EMU
+#define VT_LAUNCH(kern, grid, block, stream, ...) \
+    emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+#else
+#define VT_LAUNCH(kern, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+// ---------------------------------------------------------------------------------
+// element types
+// ---------------------------------------------------------------------------------
+struct bf16_t {
+    uint16_t v;
+};
+#ifdef VT_EMU
+struct f16_t {
+    uint16_t v;
+};
+#else
+struct f16_t {
+    _Float16 v;
+};
+#endif
+
+__device__ __forceinline__ float vt_u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __forceinline__ uint32_t vt_f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return vt_u2f(h << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = vt_f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
+#ifdef VT_EMU
+float emu_half_to_float(uint16_t h);
+uint16_t emu_float_to_half(float f);
+__device__ __forceinline__ float to_f32(f16_t x) { return emu_half_to_float(x.v); }
+#else
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x.v; }
+#endif
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float f);
+template <>
+__device__ __forceinline__ float from_f32<float>(float f) {
+    return f;
+}
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
+    bf16_t r;
+    r.v = (uint16_t)f32_to_bf16_bits(f);
+    return r;
+}
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float f) {
+    f16_t r;
+#ifdef VT_EMU
+    r.v = emu_float_to_half(f);
+#else
+    r.v = (_Float16)f;
+#endif
+    return r;
+}
+
+// 16-byte vector of T
+template <typename T>
+struct Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T e[N];
+};
+
+struct __attribute__((aligned(16))) u128 {
+    uint32_t x, y, z, w;
+};
+struct __attribute__((aligned(8))) u64v {
+    uint32_t x, y;
+};
+
+__device__ __forceinline__ u128 ld128(const void* p) { return *reinterpret_cast<const u128*>(p); }
+__device__ __forceinline__ void st128(void* p, u128 v) { *reinterpret_cast<u128*>(p) = v; }
+__device__ __forceinline__ u128 zero128() {
+    u128 z;
+    z.x = z.y = z.z = z.w = 0u;
+    return z;
+}
+
+// unpack a 16-byte vector into 16/sizeof(T) floats
+template <typename T>
+__device__ __forceinline__ void unpack16(u128 v, float* f);
+template <>
+__device__ __forceinline__ void unpack16<float>(u128 v, float* f) {
+    f[0] = vt_u2f(v.x);
+    f[1] = vt_u2f(v.y);
+    f[2] = vt_u2f(v.z);
+    f[3] = vt_u2f(v.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<bf16_t>(u128 v, float* f) {
+    f[0] = vt_u2f(v.x << 16);
+    f[1] = vt_u2f(v.x & 0xffff0000u);
+    f[2] = vt_u2f(v.y << 16);
+    f[3] = vt_u2f(v.y & 0xffff0000u);
+    f[4] = vt_u2f(v.z << 16);
+    f[5] = vt_u2f(v.z & 0xffff0000u);
+    f[6] = vt_u2f(v.w << 16);
+    f[7] = vt_u2f(v.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ u128 pack16(const float* f);
+template <>
+__device__ __forceinline__ u128 pack16<float>(const float* f) {
+    u128 v;
+    v.x = vt_f2u(f[0]);
+    v.y = vt_f2u(f[1]);
+    v.z = vt_f2u(f[2]);
+    v.w = vt_f2u(f[3]);
+    return v;
+}
+template <>
+__device__ __forceinline__ u128 pack16<bf16_t>(const float* f) {
+    u128 v;
+    v.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+    v.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+    v.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
+    v.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    return v;
+}
+
+// wavefront (64 lanes) all-reduce sum via xor shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+static inline int vt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
