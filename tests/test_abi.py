@@ -1,0 +1,89 @@
+"""CPU checks of the drop-in boundary: the gfx950 library builds, loads and exports every
+symbol declared in include/vtoonify_amd.h; the loader fails loudly when it is missing; the
+Python op surface has the reference's signatures.  No kernel is launched here."""
+import ctypes
+import inspect
+import os
+import re
+import sys
+
+import pytest
+
+from conftest import REPO
+from vtoonify_amd import _lib
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "vtoonify_amd.h")).read()
+    return sorted(set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert sorted(_lib.EXPORTED_SYMBOLS) == _declared()
+
+
+def test_gfx950_library_exports_every_symbol():
+    from vtoonify_amd import build
+    path = build.build(verbose=False)  # hipcc cross-compiles without a GPU
+    lib = ctypes.CDLL(path)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} not exported by {path}"
+    lib.vt_abi_version.restype = ctypes.c_int
+    assert lib.vt_abi_version() == 1
+    lib.vt_build_target.restype = ctypes.c_char_p
+    assert lib.vt_build_target() == b"gfx950"
+
+
+def test_loader_fails_loudly_without_library(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "DEFAULT_LIB", str(tmp_path / "libvtoonify_amd.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.VtError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected_by_the_product_library():
+    import torch
+    from vtoonify_amd import build, kernels as K
+    _lib.use_library(build.build(verbose=False))
+    with pytest.raises(_lib.VtError, match="GPU only"):
+        K.fused_bias_act(torch.zeros(1, 2, 3, 3), None, None, 3, 0, 0.2, 1.0)
+
+
+def test_op_surface_signatures_match_reference():
+    from vtoonify_amd import op
+    assert [p for p in inspect.signature(op.upfirdn2d).parameters] == ["input", "kernel", "up", "down", "pad"]
+    assert [p for p in inspect.signature(op.fused_leaky_relu).parameters] == \
+        ["input", "bias", "negative_slope", "scale"]
+    assert [p for p in inspect.signature(op.FusedLeakyReLU.__init__).parameters] == \
+        ["self", "channel", "bias", "negative_slope", "scale"]
+    assert [p for p in inspect.signature(op.conv2d_gradfix.conv2d).parameters] == \
+        ["input", "weight", "bias", "stride", "padding", "dilation", "groups"]
+    assert [p for p in inspect.signature(op.conv2d_gradfix.conv_transpose2d).parameters] == \
+        ["input", "weight", "bias", "stride", "padding", "output_padding", "groups", "dilation"]
+    assert op.conv2d_gradfix.enabled is True and op.conv2d_gradfix.weight_gradients_disabled is False
+    with op.conv2d_gradfix.no_weight_gradients():
+        assert op.conv2d_gradfix.weight_gradients_disabled is True
+    m = op.FusedLeakyReLU(7)
+    assert list(m.state_dict()) == ["bias"] and m.bias.shape == (7,)
+    # against the reference itself when it is mounted (authoring container only)
+    ref = "/root/reference/model/stylegan/op_cpu/upfirdn2d.py"
+    if os.path.exists(ref):
+        src = open(ref).read()
+        assert "def upfirdn2d(inputs, kernel, up=1, down=1, pad=(0, 0))" in src
+
+
+def test_vtoonify_signature_and_state_dict_schema():
+    import torch
+    from conftest import load_keys
+    from vtoonify_amd.vtoonify import VToonify
+    sig = inspect.signature(VToonify.forward)
+    assert list(sig.parameters) == ["self", "x", "style", "d_s", "return_mask", "return_feat"]
+    ctor = inspect.signature(VToonify.__init__).parameters
+    for name, default in [("in_size", 256), ("out_size", 1024), ("img_channels", 3), ("style_channels", 512),
+                          ("num_mlps", 8), ("channel_multiplier", 2), ("num_res_layers", 6),
+                          ("backbone", "dualstylegan")]:
+        assert ctor[name].default == default
+    for tag, bb, n in (("D", "dualstylegan", 399), ("T", "toonify", 229)):
+        want = load_keys(tag)
+        got = {k: tuple(v.shape) for k, v in VToonify(backbone=bb).state_dict().items()}
+        assert len(want) == n and got == want

@@ -1,0 +1,159 @@
+"""End-to-end parity of the HIP engine (vtoonify_amd.engine / vtoonify_amd.vtoonify) against
+(1) golden outputs of the REAL reference (tests/golden/e2e_*.npz, made with its op_cpu
+path) and (2) the CPU oracle at full benchmark size on the GPU box.
+
+Stated tolerances (un-clamped output image, relative to the reference's max-abs):
+  fp32 mode : max-abs error <= 1e-4 x max|ref|          (measured ~5e-6)
+  bf16 mode : max-abs error <= 6e-2 x max|ref|, PSNR >= 35 dB over the reference's range
+              (bf16 has no counterpart in the reference; fp32 accumulate everywhere,
+               fp32 statistics / demodulation / RGB skip path)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_keys, psnr, rel_err
+from vtoonify_amd import synth
+from vtoonify_amd.engine import VToonifyEngine
+from vtoonify_amd.vtoonify import VToonify
+
+FP32_TOL = 1e-4
+BF16_TOL, BF16_PSNR = 6e-2, 35.0
+BB = {"D": "dualstylegan", "T": "toonify"}
+_cache = {}
+
+
+def engine(tag, dtype, dev):
+    key = (tag, dtype, str(dev))
+    if key not in _cache:
+        _cache.clear()  # one resident engine at a time (D is 666 MB of fp32 weights)
+        sd = synth.synth_state_dict(load_keys(tag), 0)
+        _cache[key] = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, BB[tag], 256, dtype, dev)
+    return _cache[key]
+
+
+def check(y, ref, dtype, what=""):
+    y = y.float().cpu().numpy()
+    e = rel_err(y, ref)
+    if dtype == torch.float32:
+        assert e < FP32_TOL, f"{what}: {e:.2e}"
+    else:
+        p = psnr(y, ref, float(ref.max() - ref.min()))
+        assert e < BF16_TOL and p > BF16_PSNR, f"{what}: rel {e:.2e}, psnr {p:.1f} dB"
+
+
+@pytest.mark.parametrize("tag", ["D", "T"])
+def test_golden_fp32(dev, tag):
+    d, _ = load_golden(f"e2e_{tag}.npz")
+    eng = engine(tag, torch.float32, dev)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    for key in [k for k in d if k.startswith("y_ds")]:
+        check(eng.forward(x, s, float(key[4:])), d[key], torch.float32, key)
+    feat, skip = eng.forward(x, s, 0.5, return_feat=True)
+    check(feat, d["feat_ds0.5"], torch.float32, "feat")
+    check(skip, d["skip_ds0.5"], torch.float32, "skip")
+    if tag == "D":
+        img, masks = eng.forward(x, s, 0.5, return_mask=True)
+        check(img, d["y_ds0.5"], torch.float32, "image(return_mask)")
+        assert len(masks) == 4
+        for i, m in enumerate(masks):
+            assert tuple(m.shape) == d[f"mask{i}_ds0.5"].shape
+            check(m, d[f"mask{i}_ds0.5"], torch.float32, f"mask{i}")
+    check(eng.forward(x, s[:, 3], 0.5), d["y_wspace"], torch.float32, "W-space style")
+    # batch 2, non-square 24x40, two different styles (the groups=batch case of model.py:273-304)
+    y2 = eng.forward(torch.from_numpy(d["x2"]).to(dev), torch.from_numpy(d["style2"]).to(dev), 0.75)
+    check(y2, d["y2_ds0.75"], torch.float32, "per-sample styles")
+    check(eng.map_style(torch.from_numpy(d["zplus"]).to(dev)), d["wplus"], torch.float32, "zplus2wplus")
+
+
+@pytest.mark.parametrize("tag", ["D", "T"])
+def test_golden_bf16(dev, tag):
+    d, _ = load_golden(f"e2e_{tag}.npz")
+    eng = engine(tag, torch.bfloat16, dev)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    for key in [k for k in d if k.startswith("y_ds")]:
+        check(eng.forward(x, s, float(key[4:])), d[key], torch.bfloat16, key)
+    y2 = eng.forward(torch.from_numpy(d["x2"]).to(dev), torch.from_numpy(d["style2"]).to(dev), 0.75)
+    check(y2, d["y2_ds0.75"], torch.bfloat16, "per-sample styles")
+
+
+def test_module_dropin_surface(dev):
+    """VToonify(backbone).load_state_dict(...) ; model(x, s_w, d_s) as style_transfer.py:62-64,176."""
+    d, _ = load_golden("e2e_T.npz")
+    m = VToonify(backbone="toonify", compute_dtype=torch.float32)
+    m.load_state_dict(synth.synth_state_dict(load_keys("T"), 0))
+    m = m.to(dev)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    y = m(x, s, d_s=0.5)
+    check(y, d["y_ds0.5"], torch.float32, "module forward")
+    # Toonify ignores the style degree (model/vtoonify.py:238,257): bit-identical outputs
+    assert torch.equal(m(x, s, d_s=0.0), y) and torch.equal(m(x, s), y)
+    check(m.zplus2wplus(torch.from_numpy(d["zplus"]).to(dev)), d["wplus"], torch.float32, "zplus2wplus")
+    assert m.stylegan() is m.generator and m.backbone == "toonify"
+    with pytest.raises(Exception, match="multiples of 8"):
+        m(torch.zeros(1, 22, 30, 32, device=dev), s)
+
+
+def test_style_cache_and_determinism(dev):
+    d, _ = load_golden("e2e_D.npz")
+    eng = engine("D", torch.bfloat16, dev)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    y0 = eng.forward(x, s, 0.5)
+    assert torch.equal(eng.forward(x, s, 0.5), y0), "forward must be deterministic (noise is x0)"
+    eng.cache_styles = True
+    try:
+        y1 = eng.forward(x, s, 0.5)   # fills the cache
+        y2 = eng.forward(x, s, 0.5)   # style ops skipped
+        assert torch.equal(y1, y0) and torch.equal(y2, y0)
+        y3 = eng.forward(x, s, 1.0)   # key change -> recomputed
+        assert not torch.equal(y3, y0)
+    finally:
+        eng.cache_styles = False
+    # shared-style batch == per-frame calls (video path: s_w.repeat(B,1,1), style_transfer.py:176)
+    xb = torch.cat([x, x.flip(3)], 0)
+    yb = eng.forward(xb, s.repeat(2, 1, 1), 0.5)
+    assert torch.equal(yb[:1], y0)
+    assert torch.equal(yb[1:], eng.forward(x.flip(3).contiguous(), s, 0.5))
+
+
+# ------------------------------------------------------------------ full-size, GPU only
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,hw", [("D", (256, 256)), ("T", (144, 256))])
+def test_full_size_fp32_vs_oracle(tag, hw):
+    """BASELINE config 1/2 (22x256x256 -> 3x1024x1024) and config 3's frame size, fp32 HIP
+    vs the CPU oracle on identical seeded weights / inputs."""
+    from oracle import vtoonify_oracle as O
+    from vtoonify_amd import _lib
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    shapes = load_keys(tag)
+    sd = synth.synth_state_dict(shapes, 0)
+    x = synth.synth_frames(1, hw[0], hw[1], seed=99)
+    s = synth.synth_style(seed=17)
+    ref = O.vtoonify_forward(synth.to_numpy_sd(sd), x.numpy(), s.numpy(), 0.5, BB[tag])
+    eng = engine(tag, torch.float32, dev)
+    y = eng.forward(x.to(dev), s.to(dev), 0.5)
+    assert tuple(y.shape) == (1, 3, 4 * hw[0], 4 * hw[1])
+    check(y, ref, torch.float32, f"{tag} {hw}")
+    yb = engine(tag, torch.bfloat16, dev).forward(x.to(dev), s.to(dev), 0.5)
+    check(yb, ref, torch.bfloat16, f"{tag} {hw} bf16")
+
+
+@pytest.mark.gpu
+def test_full_size_properties():
+    """Size-independent properties at 1536x1536 output and at the demo's 360x400 crop."""
+    from vtoonify_amd import _lib
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    eng = engine("T", torch.bfloat16, dev)
+    s = synth.synth_style(seed=17).to(dev)
+    for h, w in ((384, 384), (360, 400)):
+        x = synth.synth_frames(1, h, w, seed=5).to(dev)
+        y = eng.forward(x, s, 0.3)
+        assert tuple(y.shape) == (1, 3, 4 * h, 4 * w) and torch.isfinite(y).all()
+        assert torch.equal(y, eng.forward(x, s, 0.9)), "Toonify must ignore d_s"
+    engd = engine("D", torch.bfloat16, dev)
+    x = synth.synth_frames(2, 256, 256, seed=6).to(dev)
+    yb = engd.forward(x, s.repeat(2, 1, 1), 0.5)
+    assert torch.equal(yb[1:], engd.forward(x[1:].contiguous(), s, 0.5)), "batched == per-frame"
+    assert not torch.equal(engd.forward(x[:1].contiguous(), s, 0.0), yb[:1]), "D must depend on d_s"

@@ -1,0 +1,331 @@
+"""Operator parity: HIP kernels vs the CPU oracle and the reference's golden vectors.
+
+Every test runs on two backends (conftest.dev): the host emulation of the kernel sources
+(CPU, not gpu) and the product library on a real MI355X (-m gpu).  Tolerances:
+  * upfirdn2d on integer-valued inputs / dyadic taps: BIT-EXACT
+  * fused_leaky_relu fp32: BIT-EXACT (same add / select-mul / mul roundings)
+  * fp32 contractions: 2e-5 of the output max-abs (fp32 MFMA = fmaf chain, other order)
+  * bf16 contractions: 2e-2 of the output max-abs (inputs rounded to bf16, fp32 accumulate)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import vtoonify_oracle as O
+from vtoonify_amd import kernels as K
+from vtoonify_amd import op
+
+F32_TOL, BF16_TOL = 2e-5, 2e-2
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.to(dtype) if dtype is not None else t
+
+
+def tol(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+# ------------------------------------------------------------------------------ upfirdn2d
+def test_upfirdn2d_golden(dev):
+    d, meta = load_golden("op_upfirdn2d.npz")
+    for m in meta:
+        n = m["name"]
+        up = tuple(m["up"]) if isinstance(m["up"], list) else m["up"]
+        down = tuple(m["down"]) if isinstance(m["down"], list) else m["down"]
+        y = op.upfirdn2d(T(d[n + "__x"], dev), T(d[n + "__k"], dev), up=up, down=down, pad=tuple(m["pad"]))
+        ref = d[n + "__y"]
+        assert tuple(y.shape) == ref.shape, n
+        if m["integer"]:
+            assert np.array_equal(y.cpu().numpy(), ref), f"{n}: index arithmetic not bit-exact"
+        else:
+            assert rel_err(y.cpu().numpy(), ref) < 1e-6, n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_upfirdn2d_dtypes_and_edges(dev, dtype):
+    g = np.random.default_rng(5)
+    k = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).astype(np.float32)
+    # sizes straddling the 32x64 tile, odd sizes 2h+1 (blur after conv_transpose)
+    for shape, up, down, pad in [((3, 2, 65, 129), 1, 1, (1, 1)), ((1, 3, 33, 31), 2, 1, (2, 1)),
+                                 ((2, 2, 67, 130), 1, 2, (1, 1)), ((1, 1, 5, 300), 1, 1, (2, 1)),
+                                 ((1, 2, 9, 7), (1, 2), (2, 1), (1, 0, 2, 3))]:
+        x = g.integers(-8, 9, shape).astype(np.float32)
+        y = op.upfirdn2d(T(x, dev, dtype), T(k * 4, dev), up=up, down=down, pad=pad)
+        assert y.dtype == dtype
+        ref = O.upfirdn2d(x, k * 4, up, down, pad)
+        if dtype == torch.float32:
+            assert np.array_equal(y.cpu().numpy(), ref)
+        else:  # result rounded once to the 16-bit type
+            assert rel_err(y.float().cpu().numpy(), ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+def test_upfirdn2d_properties(dev):
+    """Size-independent checks at a realistic size: linearity and the identity kernel."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1, 4, 257, 255, generator=g).to(dev)
+    b = torch.randn(1, 4, 257, 255, generator=g).to(dev)
+    k = torch.tensor(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 16.0, dtype=torch.float32)
+    f = lambda t: op.upfirdn2d(t, k, pad=(1, 1))
+    lhs, rhs = f(a + 2 * b), f(a) + 2 * f(b)
+    assert (lhs - rhs).abs().max().item() < 1e-4
+    ident = torch.ones(1, 1)
+    assert torch.equal(op.upfirdn2d(a, ident), a)
+    z = op.upfirdn2d(a, ident, up=2)  # pure zero insertion
+    assert torch.equal(z[:, :, ::2, ::2], a) and float(z[:, :, 1::2].abs().max()) == 0.0
+
+
+def test_upfirdn2d_errors(dev):
+    x = torch.zeros(1, 1, 4, 4, device=dev)
+    k = torch.ones(4, 4)
+    with pytest.raises(Exception, match="empty output"):
+        op.upfirdn2d(x, k, pad=(0, 0, -2, -2))
+    with pytest.raises(ValueError):
+        op.upfirdn2d(x[0], k)
+
+
+def test_upfirdn2d_backward_matches_oracle_adjoint(dev):
+    g = np.random.default_rng(9)
+    x = g.standard_normal((1, 2, 9, 8)).astype(np.float32)
+    k = (np.outer([1, 3, 3, 1], [1, 2, 2, 1]) / 48.0).astype(np.float32)
+    xt = T(x, dev).requires_grad_(True)
+    y = op.upfirdn2d(xt, T(k, dev), up=2, down=1, pad=(2, 1))
+    gy = g.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(T(gy, dev))
+    # adjoint identity <A x, gy> = <x, A^T gy> checked against the oracle's forward
+    lhs = float((O.upfirdn2d(x, k, 2, 1, (2, 1)) * gy).sum())
+    rhs = float((x * xt.grad.cpu().numpy()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+# ------------------------------------------------------------------------ fused_leaky_relu
+def test_fused_leaky_relu_golden_bit_exact(dev):
+    d, meta = load_golden("op_fused_act.npz")
+    for m in meta:
+        n = m["name"]
+        b = T(d[n + "__b"], dev) if m["has_bias"] else None
+        y = op.fused_leaky_relu(T(d[n + "__x"], dev), b, m["slope"], m["scale"])
+        assert np.array_equal(y.cpu().numpy(), d[n + "__y"]), n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_leaky_relu_half_types(dev, dtype):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 33, 17, generator=g)
+    b = torch.randn(6, generator=g)
+    y = op.fused_leaky_relu(x.to(dev, dtype), b.to(dev, dtype))
+    ref = O.fused_leaky_relu(x.to(dtype).float().numpy(), b.to(dtype).float().numpy())
+    assert y.dtype == dtype and rel_err(y.float().cpu().numpy(), ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+def test_fused_leaky_relu_module_and_grad(dev):
+    m = op.FusedLeakyReLU(5).to(dev)
+    with torch.no_grad():
+        m.bias.copy_(torch.linspace(-1, 1, 5))
+    x = torch.randn(3, 5, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_(True)
+    y = m(x)
+    ref = O.fused_leaky_relu(x.detach().cpu().numpy(), m.bias.detach().cpu().numpy())
+    assert np.array_equal(y.detach().cpu().numpy(), ref)
+    y.sum().backward()
+    xb = x.detach().cpu().numpy() + m.bias.detach().cpu().numpy().reshape(1, 5, 1, 1)
+    gref = np.where(xb > 0, 1.0, 0.2).astype(np.float32) * np.float32(2 ** 0.5)
+    assert np.allclose(x.grad.cpu().numpy(), gref, rtol=0, atol=1e-6)
+    assert np.allclose(m.bias.grad.cpu().numpy(), gref.sum((0, 2, 3)), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------ MFMA lane maps
+def test_mfma_lane_maps(dev):
+    """Pins the 16x16x32 bf16 / 16x16x4 f32 fragment layouts used by conv_igemm.hip with an
+    ASYMMETRIC B (a transposed C-write would fail)."""
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(16, 16, generator=g)
+    b = torch.randn(16, 16, generator=g) + torch.arange(16).float()[:, None]
+    c = K.mfma_selftest(a.to(dev), b.to(dev)).cpu()
+    assert (c - a @ b.T).abs().max().item() < 1e-4
+    a2 = torch.randn(16, 32, generator=g).bfloat16()
+    b2 = (torch.randn(16, 32, generator=g) + torch.arange(16).float()[:, None]).bfloat16()
+    c2 = K.mfma_selftest(a2.to(dev), b2.to(dev)).cpu()
+    assert (c2 - a2.float() @ b2.float().T).abs().max().item() < 1e-3
+
+
+# ----------------------------------------------------------------------------- conv_igemm
+def _conv_case(dev, dtype, N, Cin, H, W, Cout, k, stride, pad, dil, act=0, resid=False, planar=False, hint=0,
+               seed=0):
+    g = np.random.default_rng(seed)
+    x = g.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (g.standard_normal((Cout, Cin, k, k)) / math.sqrt(Cin * k * k)).astype(np.float32)
+    b = g.standard_normal(Cout).astype(np.float32)
+    cpad = (Cin + 7) // 8 * 8
+    xt = K.nchw_to_nhwc(T(x, dev), dtype)
+    wp = K.pack_conv_weight(T(w, dev), cin_dst=cpad, out_dtype=dtype)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    # the oracle sees the same operand rounding as the kernel (bf16 inputs, fp32 accumulate)
+    xq = xt.float().cpu().permute(0, 3, 1, 2)[:, :Cin].numpy()
+    wq = wp.float().cpu().numpy().reshape(Cout, k, k, cpad)[..., :Cin].transpose(0, 3, 1, 2)
+    ref = O.conv2d(xq, wq, b, stride, pad, dil)
+    gain = 1.0
+    if act == K.ACT_LRELU:
+        ref, gain = O.leaky_relu(ref, 0.2) * np.float32(2 ** 0.5), 2 ** 0.5
+    elif act == K.ACT_RELU_TANH:
+        ref = np.tanh(np.maximum(ref, 0))
+    common = dict(src0=xt, c0=cpad, ld0=cpad, n=N, h=H, w=W, out_h=Ho, out_w=Wo, weight=wp, cout=Cout, kh=k, kw=k,
+                  stride=stride, pad=pad, dil=dil, bias=T(b, dev), act=act, gain=gain, dtype=K.dt_code(dtype),
+                  tile_hint=hint, alpha=0.5 if resid else 1.0, beta=0.25 if resid else 0.0)
+    if planar:
+        out = torch.zeros((N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+        r = None
+        if resid:
+            rn = g.standard_normal((N, Cout, Ho, Wo)).astype(np.float32)
+            r, ref = T(rn, dev), ref * 0.5 + 0.25 * rn
+        K.conv2d(out=out, ld_out=0, resid=r, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, **common)
+        y = out.cpu().numpy()
+    else:
+        ldo = (Cout + 7) // 8 * 8
+        out = torch.zeros((N, Ho, Wo, ldo), dtype=dtype, device=dev)
+        r = None
+        if resid:
+            rn = g.standard_normal((N, Cout, Ho, Wo)).astype(np.float32)
+            r = K.nchw_to_nhwc(T(rn, dev), dtype, ld_out=ldo)
+            ref = ref * 0.5 + 0.25 * r.float().cpu().permute(0, 3, 1, 2)[:, :Cout].numpy()
+        K.conv2d(out=out, ld_out=ldo, resid=r, ld_res=ldo, **common)
+        y = out.float().cpu().permute(0, 3, 1, 2)[:, :Cout].numpy()
+    # operands were pre-rounded, so only accumulation order and the output rounding remain
+    return rel_err(y, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_shapes(dev, dtype):
+    t = F32_TOL if dtype == torch.float32 else 8e-3  # bf16: output rounding only
+    L, RT = K.ACT_LRELU, K.ACT_RELU_TANH
+    assert _conv_case(dev, dtype, 1, 22, 12, 9, 32, 3, 1, 1, 1, act=L) < t        # stem: 22 -> pad 24
+    assert _conv_case(dev, dtype, 2, 32, 13, 10, 64, 3, 2, 1, 1, act=L, resid=True) < t   # stride 2, odd size
+    assert _conv_case(dev, dtype, 1, 64, 9, 9, 64, 3, 1, 2, 2, act=L) < t         # dilation 2
+    assert _conv_case(dev, dtype, 1, 40, 9, 11, 128, 3, 1, 4, 4) < t              # dilation 4, K tail
+    assert _conv_case(dev, dtype, 2, 64, 7, 5, 3, 1, 1, 0, 1, planar=True, resid=True) < t   # ToRGB-like
+    assert _conv_case(dev, dtype, 1, 72, 8, 8, 1, 3, 1, 1, 1, act=RT, planar=True) < t       # mask conv
+    assert _conv_case(dev, dtype, 1, 16, 6, 6, 20, 3, 1, 1, 1) < t                # cout tail (scalar stores)
+    assert _conv_case(dev, dtype, 1, 8, 1, 1, 8, 3, 1, 1, 1) < t                  # single pixel
+
+
+@pytest.mark.parametrize("hint", [128128, 128064, 128032, 128016, 64064, 64128, 32064])
+def test_conv_every_tile(dev, hint):
+    for dtype in (torch.float32, torch.bfloat16):
+        t = F32_TOL if dtype == torch.float32 else 8e-3
+        assert _conv_case(dev, dtype, 1, 48, 10, 13, 136, 3, 1, 1, 1, act=K.ACT_LRELU, hint=hint, resid=True) < t
+
+
+def test_conv_concat_prologue_transposed(dev):
+    g = np.random.default_rng(0)
+    N, C0, C1, H, W, Co = 1, 16, 24, 7, 6, 40
+    a = g.standard_normal((N, C0, H, W)).astype(np.float32)
+    b = g.standard_normal((N, C1, H, W)).astype(np.float32)
+    w = (g.standard_normal((Co, C0 + C1, 3, 3)) / 15).astype(np.float32)
+    at = K.nchw_to_nhwc(T(a, dev), torch.float32)
+    bt = K.nchw_to_nhwc(T(b, dev), torch.float32, ld_out=32)  # wider pixel stride than channels
+    out = torch.zeros((N, H, W, Co), device=dev)
+    K.conv2d(src0=at, c0=C0, ld0=C0, src1=bt, c1=C1, ld1=32, n=N, h=H, w=W, out_h=H, out_w=W,
+             weight=K.pack_conv_weight(T(w, dev)), cout=Co, kh=3, kw=3, pad=1, out=out, ld_out=Co, dtype=0)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2).numpy(), O.conv2d(np.concatenate([a, b], 1), w, None, 1, 1, 1)) < F32_TOL
+    sc = g.standard_normal((N, C0)).astype(np.float32)
+    sh = g.standard_normal((N, C0)).astype(np.float32)
+    w2 = (g.standard_normal((Co, C0, 3, 3)) / 10).astype(np.float32)
+    out = torch.zeros((N, H, W, Co), device=dev)
+    K.conv2d(src0=at, c0=C0, ld0=C0, n=N, h=H, w=W, out_h=H, out_w=W, weight=K.pack_conv_weight(T(w2, dev)),
+             cout=Co, kh=3, kw=3, pad=1, in_scale=T(sc, dev), in_shift=T(sh, dev), out=out, ld_out=Co, dtype=0)
+    ref = O.conv2d(a * sc.reshape(N, C0, 1, 1) + sh.reshape(N, C0, 1, 1), w2, None, 1, 1, 1)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2).numpy(), ref) < F32_TOL
+
+
+def test_conv2d_gradfix_surface(dev):
+    g = np.random.default_rng(4)
+    x = g.standard_normal((2, 6, 9, 7)).astype(np.float32)
+    w = (g.standard_normal((8, 3, 3, 3)) / 5).astype(np.float32)
+    b = g.standard_normal(8).astype(np.float32)
+    y = op.conv2d_gradfix.conv2d(T(x, dev), T(w, dev), T(b, dev), stride=1, padding=1, groups=2)
+    ref = np.concatenate([O.conv2d(x[:, :3], w[:4], b[:4], 1, 1, 1), O.conv2d(x[:, 3:], w[4:], b[4:], 1, 1, 1)], 1)
+    assert rel_err(y.cpu().numpy(), ref) < F32_TOL
+    wt = (g.standard_normal((6, 5, 3, 3)) / 5).astype(np.float32)
+    yt = op.conv2d_gradfix.conv_transpose2d(T(x, dev), T(wt, dev), stride=2, padding=0)
+    assert rel_err(yt.cpu().numpy(), O.conv_transpose2d(x, wt, 2)) < F32_TOL
+    with pytest.raises(NotImplementedError):
+        op.conv2d_gradfix.conv2d(T(x, dev).requires_grad_(True), T(w, dev), groups=2)
+
+
+# ---------------------------------------------------------------- style ops / norm / glue
+def test_linear_pixelnorm(dev):
+    g = np.random.default_rng(0)
+    x = g.standard_normal((5, 24)).astype(np.float32)
+    W = g.standard_normal((40, 24)).astype(np.float32)
+    b = g.standard_normal(40).astype(np.float32)
+    y = K.linear(T(x, dev), T(W, dev), T(b, dev), w_scale=0.3, b_scale=0.01, act=K.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    assert rel_err(y.cpu().numpy(), O.fused_leaky_relu(x @ (W * np.float32(0.3)).T, b * np.float32(0.01))) < F32_TOL
+    assert rel_err(K.pixel_norm(T(x, dev)).cpu().numpy(), O.pixel_norm(x)) < 1e-6
+    d, _ = load_golden("modules.npz")
+    y = K.linear(T(d["el_act__x"], dev), T(d["el_act.weight"], dev), T(d["el_act.bias"], dev),
+                 w_scale=(1 / math.sqrt(24)) * 0.01, b_scale=0.01, act=K.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    assert rel_err(y.cpu().numpy(), d["el_act__y"]) < F32_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_styled_conv_golden(dev, dtype):
+    """ModulatedConv2d weight path + polyphase up-sampling conv vs the REAL reference's
+    StyledConv outputs (conv_transpose2d + blur + bias + lrelu), per-sample styles."""
+    d, _ = load_golden("modules.npz")
+    for name, up in (("sc_up", True), ("sc_same", False)):
+        w = d[name + ".conv.weight"][0]
+        cout, cin = w.shape[:2]
+        xs, ss, ref = d[name + "__x"], d[name + "__s"], d[name + "__y"]
+        N, _, H, W = xs.shape
+        outs = []
+        for bi in range(N):
+            s = K.linear(T(ss[bi:bi + 1].copy(), dev), T(d[name + ".conv.modulation.weight"], dev),
+                         T(d[name + ".conv.modulation.bias"], dev), w_scale=1 / math.sqrt(32))
+            fir = T(d[name + ".conv.blur.kernel"], dev) if up else None
+            wp = K.modulate_weight(T(w.copy(), dev), s[0].contiguous(), 1 / math.sqrt(cin * 9), True, fir=fir,
+                                   out_dtype=dtype)
+            xt = K.nchw_to_nhwc(T(xs[bi:bi + 1].copy(), dev), dtype)
+            f = 2 if up else 1
+            out = torch.zeros((1, H * f, W * f, cout), dtype=dtype, device=dev)
+            K.conv2d(src0=xt, c0=cin, ld0=cin, n=1, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3,
+                     pad=1, phases=4 if up else 1, out=out, ld_out=cout, dtype=K.dt_code(dtype),
+                     bias=T(d[name + ".activate.bias"], dev), act=K.ACT_LRELU, gain=2 ** 0.5)
+            outs.append(out.float().cpu().permute(0, 3, 1, 2).numpy())
+        assert rel_err(np.concatenate(outs, 0), ref) < tol(dtype), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_instnorm_adain_fusion_pack(dev, dtype):
+    g = np.random.default_rng(1)
+    N, Cc, H, W = 2, 16, 37, 29  # > 1 statistics chunk
+    x = (g.standard_normal((N, Cc, H, W)) * 2 + 1).astype(np.float32)
+    o = g.standard_normal((N, Cc, H, W)).astype(np.float32)
+    xt, ot = K.nchw_to_nhwc(T(x, dev), dtype), K.nchw_to_nhwc(T(o, dev), dtype)
+    xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+    oq = ot.float().cpu().permute(0, 3, 1, 2).numpy()
+    for use_other in (False, True):
+        ct = Cc * (2 if use_other else 1)
+        gb = g.standard_normal((N, 2 * ct)).astype(np.float32)
+        scale = torch.zeros((N, ct), device=dev)
+        shift = torch.zeros((N, ct), device=dev)
+        ws = torch.zeros(K.instnorm_ws_bytes(N, H * W, ct), dtype=torch.uint8, device=dev)
+        K.instnorm_stats(scale, shift, xt, Cc, N, H * W, Cc, ws, K.dt_code(dtype), other=ot if use_other else None,
+                         ld_other=Cc, style_gb=T(gb, dev), ld_gb=2 * ct)
+        out = torch.zeros((N, H, W, ct), dtype=dtype, device=dev)
+        K.affine_apply(out, ct, xt, Cc, scale, shift, N, H * W, Cc, K.dt_code(dtype), other=ot if use_other else None,
+                       ld_other=Cc)
+        full = np.concatenate([xq, np.abs(xq - oq)], 1) if use_other else xq
+        ref = gb[:, :ct].reshape(N, ct, 1, 1) * O.instance_norm(full) + gb[:, ct:].reshape(N, ct, 1, 1)
+        assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
+    mask = g.random((N, H, W)).astype(np.float32)
+    skip = g.standard_normal((N, 3, H, W)).astype(np.float32)
+    out = torch.full((N, H, W, Cc + 8), 7.0, dtype=dtype, device=dev)
+    K.fusion_pack(out, Cc + 8, xt, Cc, T(mask, dev), T(skip, dev), N, H * W, Cc, K.dt_code(dtype))
+    o_ = out.float().cpu().numpy()
+    t = 1e-6 if dtype == torch.float32 else 8e-3
+    assert rel_err(o_[..., :3], skip.transpose(0, 2, 3, 1)) < t and np.abs(o_[..., 3:8]).max() == 0
+    assert rel_err(o_[..., 8:], xq.transpose(0, 2, 3, 1) * mask[..., None]) < t

@@ -1,0 +1,485 @@
+"""Whole-frame executor for VToonify.forward on MI355X.
+
+Restates the data flow of the reference's VToonify.forward (model/vtoonify.py:210-277) as a
+static launch plan over libvtoonify_amd.so:
+
+  * activations live in HBM as NHWC (channels innermost, padded to 8) in the compute dtype
+    (bf16 for throughput, fp32 for parity); RGB skip images stay planar fp32;
+  * every conv is one MFMA implicit-GEMM launch with its bias / LeakyReLU / residual /
+    style-degree scaling fused in the epilogue; torch.cat never materialises (two-source
+    loader); AdaIN in the ModRes blocks is a per-channel affine applied in the conv loader;
+  * conv_transpose2d(stride 2) + 4x4 FIR blur of the up-sampling StyledConv collapses into
+    one 3x3 conv with 4*Cout polyphase filters and a pixel-shuffle store
+    (model/stylegan/model.py:273-286; derivation in DESIGN.md);
+  * everything that depends only on (style, d_s) -- T_c/T_s linears, modulation,
+    demodulated weights, AdaIN gamma/beta -- is recomputed on the GPU by the "style" op
+    list; it can be cached per style tensor (off by default in the benchmark);
+  * a plan is a flat list of (C function, prebuilt ctypes args): replaying it costs one
+    foreign call per kernel, and it is hipGraph-capturable (no allocation, no sync).
+
+Nothing here touches the CPU oracle; there is no eager-PyTorch compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC
+
+SQRT2 = math.sqrt(2.0)
+N_LATENT = 18
+_DIL = {1: 4, 2: 4, 3: 2, 4: 2, 5: 1, 6: 1}  # model/vtoonify.py:201-207
+
+
+def _pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class _Plan:
+    def __init__(self):
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.style_ops: List[Tuple] = []
+        self.enc_ops: List[Tuple] = []
+        self.gen_ops: List[Tuple] = []
+        self.keep: list = []          # ctypes objects that must outlive the plan
+        self.masks: List[torch.Tensor] = []
+        self.graph = None
+        self.graph_out = None
+
+
+class VToonifyEngine:
+    """Inference engine bound to one device and one set of weights.
+
+    state_dict: the reference's `g_ema` schema, fp32, on `device`.
+    dtype: torch.bfloat16 (fast) or torch.float32 (parity mode, exact-fp32 MFMA).
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "dualstylegan",
+                 in_size: int = 256, dtype: torch.dtype = torch.bfloat16,
+                 device: Optional[torch.device] = None, cache_styles: bool = False):
+        assert backbone in ("dualstylegan", "toonify")
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.backbone = backbone
+        self.dual = backbone == "dualstylegan"
+        self.in_size = in_size
+        self.dtype = dtype
+        self.dt = K.dt_code(dtype)
+        self.esz = 2 if dtype == torch.bfloat16 else 4
+        any_t = next(iter(state_dict.values()))
+        self.device = device or any_t.device
+        self.lib = _lib.lib()
+        if self.device.type != "cuda" and not _lib.is_emulation():
+            raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
+        self.cache_styles = cache_styles
+        self._style_key = None
+        self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
+        self.g = "generator.generator." if self.dual else "generator."
+        self.n_down = 0
+        while f"encoder.{self.n_down}.0.weight" in self.sd:
+            self.n_down += 1
+        self.n_fuse = sum(1 for lvl in range(5) if 2 ** (5 + lvl) <= in_size)
+        self._plans: Dict[tuple, _Plan] = {}
+        self._pack_static()
+
+    # ------------------------------------------------------------------ static weights
+    def _pack_static(self):
+        sd, T = self.sd, self.dtype
+        self.w: Dict[str, torch.Tensor] = {}
+        for bi in range(self.n_down):
+            for j in (0, 2):
+                self.w[f"encoder.{bi}.{j}"] = K.pack_conv_weight(sd[f"encoder.{bi}.{j}.weight"], out_dtype=T)
+        for ii in range(6):
+            for nm in ("conv", "conv2"):
+                key = f"encoder.{self.n_down}.{ii}.{nm}"
+                self.w[key] = K.pack_conv_weight(sd[key + ".weight"], out_dtype=T)
+        self.w["enc_rgb"] = K.pack_conv_weight(sd[f"encoder.{self.n_down + 1}.weight"], out_dtype=T)
+        if self.dual:
+            for ii in range(1, 7):
+                for nm in ("conv", "conv2"):
+                    w = sd[f"res.{ii}.{nm}.0.weight"]
+                    scale = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])  # EqualConv2d, model.py:101
+                    self.w[f"res.{ii}.{nm}"] = K.pack_conv_weight(w, scale=scale, out_dtype=T)
+        for fi in range(self.n_fuse):
+            if self.dual:
+                self.w[f"fusion_out.{fi}.conv"] = K.pack_conv_weight(sd[f"fusion_out.{fi}.conv.weight"], out_dtype=T)
+                self.w[f"fusion_out.{fi}.conv2"] = K.pack_conv_weight(sd[f"fusion_out.{fi}.conv2.weight"], out_dtype=T)
+            else:
+                self.w[f"fusion_out.{fi}"] = K.pack_conv_weight(sd[f"fusion_out.{fi}.weight"], out_dtype=T)
+            wsk = sd[f"fusion_skip.{fi}.weight"]  # (3, C+3, 3, 3): cat[skip(3), f_E(*m)]
+            c = wsk.shape[1] - 3
+            cmap = torch.tensor([0, 1, 2, -1, -1, -1, -1, -1] + list(range(3, c + 3)), dtype=torch.int32,
+                                device=self.device)
+            self.w[f"fusion_skip.{fi}"] = K.pack_conv_weight(wsk, cin_dst=c + 8, chan_map=cmap, out_dtype=T)
+        # modulated conv weights stay fp32 (cout, cin, k, k); they are re-modulated per style
+        self.modw = {}
+        for i in range(6, 16):
+            self.modw[f"convs.{i}"] = sd[f"{self.g}convs.{i}.conv.weight"][0].contiguous()
+        for i in range(3, 8):
+            self.modw[f"to_rgbs.{i}"] = sd[f"{self.g}to_rgbs.{i}.conv.weight"][0].contiguous()
+            self.w[f"to_rgbs.{i}.bias"] = sd[f"{self.g}to_rgbs.{i}.bias"].reshape(3).contiguous()
+        self.fir_up = sd[f"{self.g}convs.6.conv.blur.kernel"].contiguous()
+        self.fir_rgb = sd[f"{self.g}to_rgbs.3.upsample.kernel"].contiguous()
+
+    # ------------------------------------------------------------------ plan helpers
+    def _buf(self, plan: _Plan, name: str, shape, dtype=None) -> torch.Tensor:
+        t = torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+        plan.bufs[name] = t
+        return t
+
+    def _op_conv(self, ops, plan, **kw):
+        d = K.make_conv_desc(dtype=self.dt, **kw)
+        plan.keep.append(d)
+        ops.append((self.lib.vt_conv2d, (C.byref(d),), "conv"))
+
+    def _op_linear(self, ops, y, ld_y, x, ld_x, W, b, rows, w_scale=1.0, b_scale=1.0, act=ACT_NONE,
+                   slope=0.2, gain=1.0):
+        out_dim, in_dim = W.shape
+        ops.append((self.lib.vt_linear,
+                    (C.c_void_p(K._ptr(y)), ld_y, C.c_void_p(K._ptr(x)), ld_x, C.c_void_p(W.data_ptr()),
+                     C.c_void_p(b.data_ptr() if b is not None else 0), rows, in_dim, out_dim,
+                     float(w_scale), float(b_scale), act, float(slope), float(gain)), "linear"))
+
+    def _run(self, ops, stream):
+        for fn, args, what in ops:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise _lib.VtError(f"{what} failed (code {rc}): {self.lib.vt_last_error().decode()}")
+
+    # ------------------------------------------------------------------ style path
+    def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
+        """ns = number of distinct style rows prepared (1 when the batch shares a style)."""
+        sd, g, ops, lib = self.sd, self.g, plan.style_ops, self.lib
+        f32 = torch.float32
+        style_in = self._buf(plan, "style_in", (ns, N_LATENT, 512), f32)   # W+ rows
+        ada = self._buf(plan, "adastyles", (ns, N_LATENT, 512), f32)
+        ds = self._buf(plan, "d_s", (1,), f32)
+        ds1 = self._buf(plan, "d_s_rows", (ns, 1), f32)
+        rows = ns * N_LATENT
+        if self.dual:
+            # resstyles = generator.style(style)  (PixelNorm + 2 EqualLinear lr_mul=.01 fused lrelu;
+            # model/dualstylegan.py:51-55, model/vtoonify.py:212-220)
+            pn = self._buf(plan, "pn", (rows, 512), f32)
+            t1 = self._buf(plan, "tc1", (rows, 512), f32)
+            res = self._buf(plan, "resstyles", (ns, N_LATENT, 512), f32)
+            ops.append((lib.vt_pixel_norm, (C.c_void_p(pn.data_ptr()), C.c_void_p(style_in.data_ptr()), rows, 512),
+                        "pixel_norm"))
+            sc = (1.0 / math.sqrt(512)) * 0.01
+            self._op_linear(ops, t1, 512, pn, 512, sd["generator.style.1.weight"], sd["generator.style.1.bias"],
+                            rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
+            self._op_linear(ops, res, 512, t1, 512, sd["generator.style.2.weight"], sd["generator.style.2.bias"],
+                            rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
+            # adastyles[:, i] = generator.res[i](adastyles[:, i]), i = 7..17 (vtoonify.py:221-224)
+            ops.append((self._copy_op, (ada, style_in), "copy"))
+            for i in range(7, N_LATENT):
+                self._op_linear(ops, ada.data_ptr() + i * 512 * 4, N_LATENT * 512,
+                                style_in.data_ptr() + i * 512 * 4, N_LATENT * 512,
+                                sd[f"generator.res.{i}.weight"], sd[f"generator.res.{i}.bias"], ns,
+                                1.0 / math.sqrt(512), 1.0)
+        else:
+            ops.append((self._copy_op, (ada, style_in), "copy"))
+
+        # modulation vectors + modulated weights of the 15 synthesis convs (model.py:259-267)
+        plan.modw = {}
+        for lvl in range(5):
+            for name, lat, demod, up in ((f"convs.{6 + 2 * lvl}", 7 + 2 * lvl, True, True),
+                                         (f"convs.{7 + 2 * lvl}", 8 + 2 * lvl, True, False),
+                                         (f"to_rgbs.{3 + lvl}", 9 + 2 * lvl, False, False)):
+                w = self.modw[name]
+                cout, cin, k, _ = w.shape
+                s = self._buf(plan, f"s.{name}", (ns, cin), f32)
+                self._op_linear(ops, s, cin, ada.data_ptr() + lat * 512 * 4, N_LATENT * 512,
+                                sd[f"{g}{name}.conv.modulation.weight"], sd[f"{g}{name}.conv.modulation.bias"],
+                                ns, 1.0 / math.sqrt(512), 1.0)
+                phases = 4 if up else 1
+                taps = 9 if up else k * k
+                wm = self._buf(plan, f"wm.{name}", (ns, phases * cout, taps, cin))
+                plan.modw[name] = wm
+                for b in range(ns):
+                    ops.append((lib.vt_modulate_weight,
+                                (C.c_void_p(wm.data_ptr() + b * phases * cout * taps * cin * self.esz),
+                                 C.c_void_p(w.data_ptr()), C.c_void_p(s.data_ptr() + b * cin * 4), cout, cin, k,
+                                 1.0 / math.sqrt(cin * k * k), int(demod),
+                                 C.c_void_p(self.fir_up.data_ptr() if up else 0), self.dt), "modulate"))
+        if self.dual:
+            if has_res:
+                # AdaIN gamma/beta of the 6 ModRes blocks (dualstylegan.py:16-18), rows resstyles[:, ii+1]
+                for ii in range(1, 7):
+                    for nm in ("norm", "norm2"):
+                        Wl = sd[f"res.{ii}.{nm}.style.weight"]
+                        gb = self._buf(plan, f"gb.res.{ii}.{nm}", (ns, Wl.shape[0]), f32)
+                        self._op_linear(ops, gb, Wl.shape[0], plan.bufs["resstyles"].data_ptr() + ii * 512 * 4,
+                                        N_LATENT * 512, Wl, sd[f"res.{ii}.{nm}.style.bias"], ns)
+            # Fusion: label = MLP(d_s) (vtoonify.py:114-124), then AdaIN linear(label)
+            ops.append((self._fill_rows_op, (ds1, ds), "fill"))
+            for fi in range(self.n_fuse):
+                p = f"fusion_out.{fi}."
+                l0 = self._buf(plan, f"lab0.{fi}", (ns, 64), f32)
+                l1 = self._buf(plan, f"lab1.{fi}", (ns, 128), f32)
+                self._op_linear(ops, l0, 64, ds1, 1, sd[p + "linear.0.weight"], sd[p + "linear.0.bias"], ns,
+                                1.0, 1.0, ACT_LRELU, 0.2, 1.0)
+                self._op_linear(ops, l1, 128, l0, 64, sd[p + "linear.2.weight"], sd[p + "linear.2.bias"], ns,
+                                1.0, 1.0, ACT_LRELU, 0.2, 1.0)
+                Wl = sd[p + "norm.style.weight"]
+                gb = self._buf(plan, f"gb.fus.{fi}", (ns, Wl.shape[0]), f32)
+                self._op_linear(ops, gb, Wl.shape[0], l1, 128, Wl, sd[p + "norm.style.bias"], ns)
+
+    # tiny torch-side helpers used as plan ops (device-to-device copies; plumbing)
+    @staticmethod
+    def _copy_op(dst, src, stream):
+        dst.copy_(src)
+        return 0
+
+    @staticmethod
+    def _fill_rows_op(dst, src, stream):
+        dst.copy_(src.expand_as(dst))
+        return 0
+
+    # ------------------------------------------------------------------ frame path
+    def _build_plan(self, B: int, H: int, W: int, shared: bool, has_res: bool) -> _Plan:
+        sd, g, lib, dt = self.sd, self.g, self.lib, self.dt
+        plan = _Plan()
+        ns = 1 if shared else B
+        self._build_style_ops(plan, ns, has_res)
+        f32 = torch.float32
+        ops = plan.enc_ops
+        ds = plan.bufs["d_s"]
+
+        # ---- content encoder (model/vtoonify.py:160-183, 226-242) -------------------
+        cin0 = sd["encoder.0.0.weight"].shape[1]
+        x_nhwc = self._buf(plan, "x_nhwc", (B, H, W, _pad8(cin0)))
+        plan.cin0 = cin0
+        cur, cc, h, w = x_nhwc, _pad8(cin0), H, W
+        feats = []
+        for bi in range(self.n_down):
+            stride = 1 if bi == 0 else 2
+            for j in (0, 2):
+                wt = sd[f"encoder.{bi}.{j}.weight"]
+                co = wt.shape[0]
+                st = stride if j == 0 else 1
+                ho, wo = (h + 2 - 3) // st + 1, (w + 2 - 3) // st + 1
+                out = self._buf(plan, f"enc{bi}.{j}", (B, ho, wo, co))
+                self._op_conv(ops, plan, src0=cur, c0=cc, ld0=cc, n=B, h=h, w=w, out_h=ho, out_w=wo,
+                              weight=self.w[f"encoder.{bi}.{j}"], cout=co, kh=3, kw=3, stride=st, pad=1,
+                              bias=sd[f"encoder.{bi}.{j}.bias"], act=ACT_LRELU, slope=0.2, out=out, ld_out=co)
+                cur, cc, h, w = out, co, ho, wo
+            feats.append((cur, cc, h, w))
+        feats = feats[::-1]
+        # ---- 6 x (VToonifyResBlock [+ AdaResBlock]) at H/8 (vtoonify.py:92-104, 235-239) --
+        cf = cc
+        tmp = self._buf(plan, "res_tmp", (B, h, w, cf))
+        ping = [self._buf(plan, "feat_a", (B, h, w, cf)), self._buf(plan, "feat_b", (B, h, w, cf))]
+        hw = h * w
+        if self.dual and has_res:
+            sc1 = self._buf(plan, "in_scale", (B, cf), f32)
+            sh1 = self._buf(plan, "in_shift", (B, cf), f32)
+            ws = self._buf(plan, "in_ws", (max(K.instnorm_ws_bytes(B, hw, cf), 16),), torch.uint8)
+        feat = cur
+        pp = 0
+        rk = f"encoder.{self.n_down}"
+        for ii in range(6):
+            self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                          weight=self.w[f"{rk}.{ii}.conv"], cout=cf, kh=3, kw=3, pad=1,
+                          bias=sd[f"{rk}.{ii}.conv.bias"], act=ACT_LRELU, out=tmp, ld_out=cf)
+            nxt = ping[pp]; pp ^= 1
+            self._op_conv(ops, plan, src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                          weight=self.w[f"{rk}.{ii}.conv2"], cout=cf, kh=3, kw=3, pad=1,
+                          bias=sd[f"{rk}.{ii}.conv2.bias"], act=ACT_LRELU, alpha=1 / SQRT2, beta=1 / SQRT2,
+                          resid=feat, ld_res=cf, out=nxt, ld_out=cf)
+            feat = nxt
+            if self.dual and has_res:
+                r = ii + 1
+                dil = _DIL[r]
+                # AdaResBlock (dualstylegan.py:38-45): AdaIN folded into the conv loader
+                for nm, src, dst in (("norm", feat, tmp), ("norm2", tmp, None)):
+                    gb = plan.bufs[f"gb.res.{r}.{nm}"]
+                    ops.append((lib.vt_instnorm_stats,
+                                (C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()), C.c_void_p(src.data_ptr()),
+                                 cf, C.c_void_p(0), 0, B, hw, cf, C.c_void_p(gb.data_ptr()),
+                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt), "instnorm"))
+                    cn = "conv" if nm == "norm" else "conv2"
+                    if dst is not None:
+                        self._op_conv(ops, plan, src0=src, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                                      weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
+                                      in_scale=sc1, in_shift=sh1, bias=sd[f"res.{r}.{cn}.1.bias"],
+                                      act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf)
+                    else:
+                        nxt = ping[pp]; pp ^= 1
+                        # out * d_s + skip  (d_s read from device memory: graph-replay safe)
+                        self._op_conv(ops, plan, src0=src, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                                      weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
+                                      in_scale=sc1, in_shift=sh1, bias=sd[f"res.{r}.{cn}.1.bias"],
+                                      act=ACT_LRELU, gain=SQRT2, alpha_dev=ds, beta=1.0, resid=feat, ld_res=cf,
+                                      out=nxt, ld_out=cf)
+                        feat = nxt
+        plan.feat = (feat, cf, h, w)
+        skip = self._buf(plan, "skip_enc", (B, 3, h, w), f32)
+        self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                      weight=self.w["enc_rgb"], cout=3, kh=1, kw=1, bias=sd[f"encoder.{self.n_down + 1}.bias"],
+                      out=skip, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+        plan.skip_enc = skip
+
+        # ---- synthesis levels (vtoonify.py:245-272) ------------------------------------
+        ops = plan.gen_ops
+        out, co = feat, cf
+        for lvl in range(5):
+            hw = h * w
+            if lvl < self.n_fuse:
+                f_e, ce, he, we = feats[lvl]
+                assert (he, we) == (h, w) and ce == co, "encoder/generator size mismatch (H, W must be multiples of 8)"
+                fem = self._buf(plan, f"fem{lvl}", (B, h, w, co + 8))
+                mask = None
+                if self.dual:
+                    # Fusion.forward (vtoonify.py:122-128)
+                    sc = self._buf(plan, f"fsc{lvl}", (B, 2 * co), f32)
+                    sh = self._buf(plan, f"fsh{lvl}", (B, 2 * co), f32)
+                    ws = self._buf(plan, f"fws{lvl}", (max(K.instnorm_ws_bytes(B, hw, 2 * co), 16),), torch.uint8)
+                    gb = plan.bufs[f"gb.fus.{lvl}"]
+                    ops.append((lib.vt_instnorm_stats,
+                                (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
+                                 C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
+                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt), "instnorm"))
+                    nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                    ops.append((lib.vt_affine_apply,
+                                (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                 C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
+                                 B, hw, co, dt), "affine"))
+                    mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
+                    self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
+                                  weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
+                                  bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
+                                  out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                    plan.masks.append(mask)
+                ops.append((lib.vt_fusion_pack,
+                            (C.c_void_p(fem.data_ptr()), co + 8, C.c_void_p(f_e.data_ptr()), co,
+                             C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
+                             B, hw, co, dt), "fusion_pack"))
+                fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
+                wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
+                self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + 8 * self.esz, c1=co,
+                              ld1=co + 8, n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[wkey], cout=co, kh=3,
+                              kw=3, pad=1, bias=sd[wkey + ".bias"], out=fo, ld_out=co)
+                sk2 = self._buf(plan, f"fskip{lvl}", (B, 3, h, w), f32)
+                self._op_conv(ops, plan, src0=fem, c0=co + 8, ld0=co + 8, n=B, h=h, w=w, out_h=h, out_w=w,
+                              weight=self.w[f"fusion_skip.{lvl}"], cout=3, kh=3, kw=3, pad=1,
+                              bias=sd[f"fusion_skip.{lvl}.bias"], out=sk2, ld_out=0, out_layout=OUT_NCHW,
+                              out_dtype=K.VT_F32)
+                out, skip = fo, sk2
+            n1, n2, n3 = f"convs.{6 + 2 * lvl}", f"convs.{7 + 2 * lvl}", f"to_rgbs.{3 + lvl}"
+            c1o = self.modw[n1].shape[0]
+            up = self._buf(plan, f"up{lvl}", (B, 2 * h, 2 * w, c1o))
+            o2 = self._buf(plan, f"gout{lvl}", (B, 2 * h, 2 * w, c1o))
+            rgb = self._buf(plan, f"rgb{lvl}", (B, 3, 2 * h, 2 * w), f32)
+            # skip = Upsample(skip): upfirdn2d up=2 pad=(2,1) (model.py:32-50), fp32 planes
+            ops.append((lib.vt_upfirdn2d,
+                        (C.c_void_p(rgb.data_ptr()), C.c_void_p(skip.data_ptr()), C.c_void_p(self.fir_rgb.data_ptr()),
+                         B * 3, h, w, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, K.VT_F32), "upfirdn2d"))
+            groups = [(0, B)] if ns == 1 else [(b, 1) for b in range(B)]
+            for b0, nb in groups:
+                sidx = 0 if ns == 1 else b0
+                wm1 = plan.modw[n1][sidx]
+                wm2 = plan.modw[n2][sidx]
+                wm3 = plan.modw[n3][sidx]
+                # StyledConv(upsample): polyphase 3x3 with 4*Cout filters + pixel shuffle
+                self._op_conv(ops, plan, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co, ld0=co, n=nb, h=h,
+                              w=w, out_h=h, out_w=w, weight=wm1, cout=c1o, kh=3, kw=3, pad=1, phases=4,
+                              bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
+                              out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
+                self._op_conv(ops, plan, src0=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
+                              h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm2, cout=c1o, kh=3, kw=3, pad=1,
+                              bias=sd[f"{g}{n2}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
+                              out=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
+                # ToRGB: 1x1 modulated conv (no demod) + bias + up-sampled skip (model.py:383-392)
+                self._op_conv(ops, plan, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
+                              h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
+                              bias=self.w[f"{n3}.bias"], beta=1.0, resid=rgb.data_ptr() + b0 * 3 * 4 * hw * 4,
+                              out=rgb.data_ptr() + b0 * 3 * 4 * hw * 4, ld_out=0, out_layout=OUT_NCHW,
+                              out_dtype=K.VT_F32)
+            out, co, skip, h, w = o2, c1o, rgb, 2 * h, 2 * w
+        plan.image = skip
+        return plan
+
+    # ------------------------------------------------------------------ public API
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def _rows_equal(self, style: torch.Tensor) -> bool:
+        return bool((style == style[:1]).all().item())
+
+    def map_style(self, z: torch.Tensor) -> torch.Tensor:
+        """VToonify.zplus2wplus (model/vtoonify.py:285-286): 8-layer mapping network."""
+        sd, g = self.sd, self.g
+        shape = z.shape
+        x = z.detach().to(self.device, torch.float32).reshape(-1, shape[-1]).contiguous()
+        x = K.pixel_norm(x)
+        sc = (1.0 / math.sqrt(512)) * 0.01
+        for i in range(1, 9):
+            x = K.linear(x, sd[f"{g}style.{i}.weight"], sd[f"{g}style.{i}.bias"], sc, 0.01, ACT_LRELU, 0.2, SQRT2)
+        return x.reshape(shape)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, style: torch.Tensor, d_s=None, return_mask: bool = False,
+                return_feat: bool = False, shared_style: Optional[bool] = None,
+                use_graph: bool = False) -> torch.Tensor:
+        if x.device != self.device and not (x.device.type == self.device.type == "cpu"):
+            raise _lib.VtError(f"input on {x.device}, engine on {self.device}")
+        B, cin, H, W = x.shape
+        if H % 8 or W % 8:
+            raise _lib.VtError("H and W must be multiples of 8 (util.py:184-187 crops to //8*8)")
+        if self.dual and d_s is None:
+            raise TypeError("VToonify-D needs a style degree d_s (model/vtoonify.py:124)")
+        d_s = 0.0 if d_s is None else float(d_s)
+        style = style.detach().to(self.device, torch.float32)
+        if style.ndim == 2:  # W space (vtoonify.py:212-215)
+            style = style[:, None, :].expand(-1, N_LATENT, -1)
+            wspace = True
+        else:
+            wspace = False
+        if style.shape[0] not in (1, B):
+            raise _lib.VtError("style batch must be 1 or match the frame batch")
+        if shared_style is None:
+            shared_style = style.shape[0] == 1 or B == 1 or self._rows_equal(style)
+        has_res = self.dual and d_s != 0.0  # AdaResBlock early-out (dualstylegan.py:40-41)
+        key = (B, H, W, bool(shared_style), has_res)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build_plan(B, H, W, bool(shared_style), has_res)
+            self._plans[key] = plan
+        if cin != plan.cin0:
+            raise _lib.VtError(f"expected {plan.cin0} input channels, got {cin}")
+        stream = self._stream()
+        # ---- per-call inputs into the plan's static buffers ---------------------------
+        srows = style[:1] if shared_style else style
+        skey = (id(plan), srows.data_ptr(), getattr(srows, "_version", 0), d_s, wspace)
+        need_style = not (self.cache_styles and skey == self._style_key)
+        xs = x.detach().contiguous()
+        rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(plan.bufs["x_nhwc"].data_ptr()), plan.bufs["x_nhwc"].shape[-1],
+                                      C.c_void_p(xs.data_ptr()), B, cin, H * W, K.dt_code(xs.dtype), self.dt, stream)
+        _lib.check(rc, "vt_nchw_to_nhwc")
+        if need_style:
+            plan.bufs["style_in"].copy_(srows)
+            plan.bufs["d_s"].fill_(d_s)
+            if self.dual and wspace:
+                # W-space input: resstyles = generator.style(style) per row is identical for
+                # all 18 rows, which the W+ path reproduces because every row equals `style`.
+                pass
+            self._run(plan.style_ops, stream)
+            self._style_key = skey if self.cache_styles else None
+        self._run(plan.enc_ops, stream)
+        if return_feat:
+            feat, cf, h, w = plan.feat
+            f = K.nhwc_to_nchw(feat, cf, B, cf, h, w, self.dtype, torch.float32, self.device, feat)
+            return f, plan.skip_enc.clone()
+        self._run(plan.gen_ops, stream)
+        image = plan.image.clone()
+        if return_mask and self.dual:
+            return image, [m.clone() for m in plan.masks]
+        return image
+
+    __call__ = forward

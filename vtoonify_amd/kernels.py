@@ -81,38 +81,46 @@ def fused_bias_act(x, bias, refer, act, grad, alpha, scale):
     return out
 
 
-def conv2d(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw, out, ld_out, dtype,
-           src1=None, c1=0, ld1=0, stride=1, pad=0, dil=1, phases=1, transposed=0, in_scale=None,
-           in_shift=None, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, alpha=1.0, beta=0.0,
-           alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None, tile_hint=0,
-           stream_of=None):
-    """Pointers may be tensors or raw ints (sub-views: pass tensor.data_ptr() + offset)."""
-    def ptr(v):
-        if v is None:
-            return None
-        if isinstance(v, torch.Tensor):
-            return v.data_ptr()
-        return int(v)
+def _ptr(v):
+    if v is None:
+        return None
+    if isinstance(v, torch.Tensor):
+        return v.data_ptr()
+    return int(v)
 
+
+def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw, out, ld_out, dtype,
+                   src1=None, c1=0, ld1=0, stride=1, pad=0, dil=1, phases=1, transposed=0, in_scale=None,
+                   in_shift=None, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, alpha=1.0, beta=0.0,
+                   alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None,
+                   tile_hint=0) -> ConvDesc:
+    """Fill a vt_conv_desc.  Pointers may be tensors or raw ints (sub-views: data_ptr()+offset)."""
     d = ConvDesc()
-    d.src0, d.src1 = ptr(src0), ptr(src1)
+    d.src0, d.src1 = _ptr(src0), _ptr(src1)
     d.c0, d.c1, d.ld0, d.ld1 = c0, c1, ld0, ld1
     d.n, d.h, d.w, d.out_h, d.out_w = n, h, w, out_h, out_w
-    d.weight = ptr(weight)
+    d.weight = _ptr(weight)
     d.cout = cout
     d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
     d.phases, d.transposed = phases, transposed
-    d.in_scale, d.in_shift = ptr(in_scale), ptr(in_shift)
-    d.bias = ptr(bias)
+    d.in_scale, d.in_shift = _ptr(in_scale), _ptr(in_shift)
+    d.bias = _ptr(bias)
     d.act, d.slope, d.gain, d.alpha, d.beta = act, slope, gain, alpha, beta
-    d.alpha_dev = ptr(alpha_dev)
-    d.resid, d.ld_res = ptr(resid), ld_res
-    d.out, d.ld_out = ptr(out), ld_out
+    d.alpha_dev = _ptr(alpha_dev)
+    d.resid, d.ld_res = _ptr(resid), ld_res
+    d.out, d.ld_out = _ptr(out), ld_out
     d.out_layout = out_layout
     d.dtype = dtype
     d.out_dtype = dtype if out_dtype is None else out_dtype
     d.tile_hint = tile_hint
-    t = stream_of if stream_of is not None else (out if isinstance(out, torch.Tensor) else src0)
+    return d
+
+
+def conv2d(*, stream_of=None, **kw):
+    d = make_conv_desc(**kw)
+    t = stream_of
+    if t is None:
+        t = kw["out"] if isinstance(kw["out"], torch.Tensor) else kw["src0"]
     _lib.check(_lib.lib().vt_conv2d(C.byref(d), _stream(t)), "vt_conv2d")
 
 
