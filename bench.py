@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of VToonify-D inference at 1024x1024 output on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (VToonify.forward, model/vtoonify.py:210-277 of the
+reference) over one batch of synthetic frames already resident in HBM.  The workload at
+N=1 is BASELINE.json configs[1]: a single 22x256x256 frame -> 3x1024x1024, VToonify-D,
+bf16 compute (fp32 accumulate / statistics / RGB skip path), seeded synthetic weights.
+Nothing is cached across steps: the style path (T_c/T_s linears, weight modulation +
+demodulation, AdaIN gamma/beta) is recomputed every frame like the reference does.
+
+For N>1 every rank processes its own shard of frames (weak scaling: per-GPU work fixed);
+the only collective is the one-time RCCL broadcast of weights + style code before the timed
+region (vtoonify_amd/frames.py).  Timing: barrier + synchronize on both sides of exactly K
+steps, MAX over ranks; value = N*K*batch / that time.
+
+The JSON line also carries
+  roofline      the dominant kernel of the frame (largest share of GPU time), its achieved
+                ALGORITHMIC flop/s (or byte/s) = work per launch / mean launch duration measured
+                with HIP events on the launch stream, against the MI355X peak;
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's op_cpu path)
+                timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA = vector rate
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def state_shapes(backbone: str):
+    """state_dict schema (key -> shape) of VToonify(backbone) without allocating weights."""
+    from vtoonify_amd.vtoonify import VToonify
+    with torch.device("meta"):
+        m = VToonify(backbone=backbone)
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
+    """Time the CPU oracle on the host cores.  Sample: ONE frame of the benchmark workload when
+    that fits the budget, otherwise a centre crop scaled to it (cost is linear in H*W)."""
+    import numpy as np
+    from oracle import vtoonify_oracle as O  # the checker, timed as the CPU baseline
+    from vtoonify_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O.set_backend("torch")  # dense contractions through F.conv2d on CPU, like the reference's op_cpu path
+    sd = synth.to_numpy_sd(synth.synth_state_dict(state_shapes(backbone), 0))
+    s = synth.synth_style(seed=17).numpy()
+    # probe at 64x64 to size the sample
+    xp = synth.synth_frames(1, 64, 64, seed=1).numpy()
+    O.vtoonify_forward(sd, xp, s, 0.5, backbone)
+    t0 = time.perf_counter()
+    O.vtoonify_forward(sd, xp, s, 0.5, backbone)
+    t_probe = time.perf_counter() - t0
+    scale = (height * width) / (64 * 64)
+    h, w = height, width
+    while t_probe * (h * w) / (64 * 64) > budget_s and h > 64:
+        h, w = h // 2, w // 2
+    x = synth.synth_frames(1, h, w, seed=2).numpy()
+    t0 = time.perf_counter()
+    y = O.vtoonify_forward(sd, x, s, 0.5, backbone)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(y).all()
+    # frames/s of the benchmark workload: scale the sample linearly in pixels
+    fps = 1.0 / (dt * (height * width) / (h * w))
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+            "backend": getattr(O, "BACKEND", "numpy"),
+            "sample": f"1 frame 22x{h}x{w} -> 3x{4 * h}x{4 * w} fp32 through oracle/vtoonify_oracle.py "
+                      f"in {dt:.2f} s, scaled x{(height * width) // (h * w)} in pixels to the "
+                      f"22x{height}x{width} workload"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--height", type=int, default=256, help="input height (output is 4x)")
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--backbone", default="dualstylegan", choices=["dualstylegan", "toonify"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--d-s", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
+    ap.add_argument("--op-iters", type=int, default=5, help="instrumented frames for per-kernel timing")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table (stderr)")
+    args = ap.parse_args()
+
+    from vtoonify_amd import _lib, frames, synth
+    from vtoonify_amd.engine import VToonifyEngine
+
+    rank, local_rank, ws = frames.init()
+    if ws != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the package has no CPU path)")
+    _lib.use_library(_lib.DEFAULT_LIB)
+    assert not _lib.is_emulation()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, H, W = args.batch, args.height, args.width
+
+    # ---- weights + style: synthesised on rank 0, one RCCL broadcast (frames.py) ------------
+    shapes = state_shapes(args.backbone)
+    sd = synth.synth_state_dict(shapes, 0) if rank == 0 else None
+    t0 = time.perf_counter()
+    sd_dev = frames.broadcast_state_dict(shapes, sd, dev)
+    style, d_s = frames.broadcast_style(synth.synth_style(seed=17) if rank == 0 else None,
+                                        args.d_s if rank == 0 else None, dev)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    del sd
+    eng = VToonifyEngine(sd_dev, args.backbone, 256, dtype, dev)
+    use_graph = not args.no_graph
+
+    # ---- this rank's shard of the synthetic video, resident in HBM -------------------------
+    pool = [synth.synth_frames(B, H, W, seed=1000 * rank + i).to(dev) for i in range(4)]
+
+    def step(i):
+        return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph)
+
+    for i in range(args.warmup):
+        y = step(i)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(y).all())
+
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if ws > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        fps = ws * args.steps * B / elapsed
+        # ---- per-kernel timing (HIP events on the launch stream), dominant kernel ----------
+        plan = eng.plan_for(B, H, W, True, d_s != 0.0)
+        per_op = eng.time_ops(plan, iters=max(1, args.op_iters), with_style=True)
+        classes = {}
+        for info, ms in per_op:
+            c = classes.setdefault(info["kernel"], {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
+            c["ms"] += ms
+            c["launches"] += 1
+            c["flops"] += info["flops"]
+            c["bytes"] += info["bytes"]
+        frame_ms = sum(c["ms"] for c in classes.values())
+        rows = []
+        for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
+            sec = c["ms"] * 1e-3
+            tf = c["flops"] / sec / 1e12 if sec > 0 else 0.0
+            gbs = c["bytes"] / sec / 1e9 if sec > 0 else 0.0
+            peak_tf = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+            # which roof bounds this kernel: compare its arithmetic intensity with the ridge
+            ai = c["flops"] / max(c["bytes"], 1)
+            bound = "mfma" if ai > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+            rows.append({"kernel": name, "launches": c["launches"], "ms_per_frame": c["ms"],
+                         "share": c["ms"] / frame_ms if frame_ms else 0.0,
+                         "avg_launch_us": 1e3 * c["ms"] / c["launches"], "bound": bound,
+                         "tflops": tf, "gbs": gbs,
+                         "frac": (tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS)})
+        dom = rows[0]
+        if dom["bound"] == "mfma":
+            roofline = {"bound": "mfma", "achieved": dom["tflops"],
+                        "peak": PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS,
+                        "unit": "TFLOP/s"}
+        else:
+            roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        roofline["traffic"] = None
+        roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
+                         "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
+                         "kernel_sum_ms_per_frame": frame_ms})
+        if args.kernels:
+            for r in rows:
+                print(f"{r['kernel']:<36} n={r['launches']:3d} {r['ms_per_frame']:8.3f} ms {100 * r['share']:5.1f}% "
+                      f"{r['bound']:>4} {r['tflops']:8.1f} TF/s {r['gbs']:8.1f} GB/s frac {r['frac']:.3f}",
+                      file=sys.stderr)
+            for info, ms in per_op:
+                if info.get("name") == "conv":
+                    print(f"   {info['kernel']:<30} m={info['m']:8d} cout={info['cout']:5d} k={info['k']:5d} "
+                          f"{1e3 * ms:9.1f} us {info['flops'] / ms / 1e9:8.1f} TF/s "
+                          f"{info['bytes'] / ms / 1e6:8.1f} GB/s", file=sys.stderr)
+                else:
+                    print(f"   {info['kernel']:<30} {1e3 * ms:9.1f} us {info['bytes'] / ms / 1e6:8.1f} GB/s",
+                          file=sys.stderr)
+        result = {
+            "metric": "frames/sec at 1024x1024 VToonify-D inference" if (4 * H, 4 * W) == (1024, 1024)
+            and args.backbone == "dualstylegan" else f"frames/sec at {4 * W}x{4 * H} VToonify inference",
+            "value": fps, "unit": "frames/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"VToonify-{'D' if args.backbone == 'dualstylegan' else 'T'} "
+                                   f"22x{H}x{W} -> 3x{4 * H}x{4 * W}, batch {B} per GPU, d_s={d_s}, "
+                                   f"seeded synthetic weights, style path recomputed every frame",
+                       "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{ws}",
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "weight_broadcast_s": t_bcast},
+            "roofline": roofline,
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+                        for r in rows[:8]],
+        }
+    # the CPU baseline runs after the GPU numbers are final (rank 0, single-GPU runs only)
+    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+        del eng, sd_dev
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(args.backbone, H, W, args.cpu_budget)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,9 @@ typedef struct vt_conv_desc {
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
+/* The workgroup tile vt_conv2d would run `desc` on, as BM*1000+BN (-1: invalid descriptor).
+ * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
+int vt_conv2d_tile(const vt_conv_desc* desc);
 
 /* Plain conv weight (cout, cin_src, kh, kw) fp32 -> packed [cout][kh*kw][cin_dst],
  * multiplied by `scale` (EqualConv2d's 1/sqrt(fan_in), model/stylegan/model.py:101,117).

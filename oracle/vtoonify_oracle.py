@@ -18,6 +18,16 @@ here from their published definitions (cross-correlation, zero padding; biased
 variance, eps inside the sqrt).
 
 All tensors are numpy fp32, NCHW, exactly the reference's layout.
+
+Backends for the three dense contractions (conv2d / conv_transpose2d / linear):
+  "numpy"  (default) the plain restatement below -- one BLAS matmul per filter tap;
+  "torch"  the very functions the reference calls, torch.nn.functional.conv2d /
+           conv_transpose2d / linear on CPU tensors (op/conv2d_gradfix.py:34-42,66-75,
+           model/stylegan/model.py:154-160).  ~100x faster at the 22x256x256 benchmark size,
+           which the numpy form needs minutes for; tests/test_oracle_golden.py pins both
+           backends against the same golden vectors and against each other.  Everything else
+           (upfirdn2d, fused_leaky_relu, modulation, AdaIN, the graph) is numpy either way.
+Select with set_backend(); full-size GPU parity tests and bench.py's cpu_baseline use "torch".
 """
 from __future__ import annotations
 
@@ -27,6 +37,21 @@ import numpy as np
 
 F32 = np.float32
 SQRT2 = F32(2.0 ** 0.5)
+BACKEND = "numpy"
+
+
+def set_backend(name: str) -> str:
+    """Choose how conv2d / conv_transpose2d / linear are evaluated; returns the old setting."""
+    global BACKEND
+    if name not in ("numpy", "torch"):
+        raise ValueError(name)
+    old, BACKEND = BACKEND, name
+    return old
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
 
 
 # --------------------------------------------------------------------------------------
@@ -97,6 +122,10 @@ def conv2d(x, w, b=None, stride=1, padding=0, dilation=1):
     op/conv2d_gradfix.py:34-42 and the nn.Conv2d modules of model/vtoonify.py)."""
     x = np.asarray(x, dtype=F32)
     w = np.asarray(w, dtype=F32)
+    if BACKEND == "torch":
+        import torch.nn.functional as TF
+        return TF.conv2d(_t(x), _t(w), None if b is None else _t(b), stride=stride, padding=padding,
+                         dilation=dilation).numpy()
     n, cin, h, wd = x.shape
     cout, cin2, kh, kw = w.shape
     assert cin == cin2
@@ -121,6 +150,9 @@ def conv_transpose2d(x, w, stride=2):
     scatters its kh x kw patch (model/stylegan/model.py:281-283)."""
     x = np.asarray(x, dtype=F32)
     w = np.asarray(w, dtype=F32)
+    if BACKEND == "torch":
+        import torch.nn.functional as TF
+        return TF.conv_transpose2d(_t(x), _t(w), stride=stride).numpy()
     n, cin, h, wd = x.shape
     cin2, cout, kh, kw = w.shape
     assert cin == cin2
@@ -136,6 +168,9 @@ def conv_transpose2d(x, w, stride=2):
 
 
 def linear(x, w, b=None):
+    if BACKEND == "torch":
+        import torch.nn.functional as TF
+        return TF.linear(_t(x), _t(w), None if b is None else _t(b)).numpy()
     y = np.asarray(x, dtype=F32) @ np.asarray(w, dtype=F32).T
     if b is not None:
         y = y + np.asarray(b, dtype=F32)

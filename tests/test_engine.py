@@ -130,7 +130,11 @@ def test_full_size_fp32_vs_oracle(tag, hw):
     sd = synth.synth_state_dict(shapes, 0)
     x = synth.synth_frames(1, hw[0], hw[1], seed=99)
     s = synth.synth_style(seed=17)
-    ref = O.vtoonify_forward(synth.to_numpy_sd(sd), x.numpy(), s.numpy(), 0.5, BB[tag])
+    old = O.set_backend("torch")  # full size: minutes with the numpy contractions, seconds with F.conv2d
+    try:
+        ref = O.vtoonify_forward(synth.to_numpy_sd(sd), x.numpy(), s.numpy(), 0.5, BB[tag])
+    finally:
+        O.set_backend(old)
     eng = engine(tag, torch.float32, dev)
     y = eng.forward(x.to(dev), s.to(dev), 0.5)
     assert tuple(y.shape) == (1, 3, 4 * hw[0], 4 * hw[1])

@@ -16,6 +16,14 @@ from vtoonify_amd import synth
 TOL = 2e-5
 
 
+@pytest.fixture(params=["numpy", "torch"])
+def backend(request):
+    """Both evaluations of the dense contractions (oracle docstring) are pinned to the goldens."""
+    old = O.set_backend(request.param)
+    yield request.param
+    O.set_backend(old)
+
+
 def test_upfirdn2d_all_cases():
     d, meta = load_golden("op_upfirdn2d.npz")
     assert len(meta) >= 12
@@ -45,7 +53,7 @@ def _sub(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix) and "__" not in k}
 
 
-def test_modules():
+def test_modules(backend):
     d, _ = load_golden("modules.npz")
     # StyledConv up / same
     for name, up in [("sc_up", True), ("sc_same", False)]:
@@ -88,7 +96,7 @@ def test_modules():
 
 
 @pytest.mark.parametrize("tag,bb", [("D", "dualstylegan"), ("T", "toonify")])
-def test_end_to_end(tag, bb):
+def test_end_to_end(tag, bb, backend):
     d, _ = load_golden(f"e2e_{tag}.npz")
     shapes = load_keys(tag)
     assert len(shapes) == (399 if tag == "D" else 229)

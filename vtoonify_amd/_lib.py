@@ -57,6 +57,7 @@ _SIGS = {
     "vt_fused_bias_act": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                        C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "vt_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "vt_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "vt_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "vt_modulate_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

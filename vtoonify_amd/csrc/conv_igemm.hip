@@ -376,22 +376,28 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     return vt_check_launch("vt_conv2d");
 }
 
-template <typename T>
-int dispatch(const ConvArgs& a, int hint, vt_stream stream) {
-    int bm = 0, bn = 0;
+// Tile selection shared by vt_conv2d and vt_conv2d_tile (bench / profiling use the latter to
+// name the kernel instance a descriptor runs on).
+static void choose_tile(const ConvArgs& a, int hint, int& bm, int& bn) {
     if (hint > 0) {
         bm = hint / 1000;
         bn = hint % 1000;
-    } else {
-        bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
-        bm = 128;
-        // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
-        auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(a.M, m) * vt_cdiv(a.coutT, n); };
-        if (bn == 128 && tiles(128, 128) < 512) bn = 64;
-        if (tiles(bm, bn) < 512) bm = 64;
-        if (bn == 64 && tiles(bm, bn) < 256 && bm == 64) bm = 32;
-        if (bn == 16 || bn == 32) bm = 128;
+        return;
     }
+    bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
+    bm = 128;
+    // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
+    auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(a.M, m) * vt_cdiv(a.coutT, n); };
+    if (bn == 128 && tiles(128, 128) < 512) bn = 64;
+    if (tiles(bm, bn) < 512) bm = 64;
+    if (bn == 64 && tiles(bm, bn) < 256 && bm == 64) bm = 32;
+    if (bn == 16 || bn == 32) bm = 128;
+}
+
+template <typename T>
+int dispatch(const ConvArgs& a, int hint, vt_stream stream) {
+    int bm = 0, bn = 0;
+    choose_tile(a, hint, bm, bn);
 #define VT_CFG(M_, N_, WM_, WN_) \
     if (bm == M_ && bn == N_) return launch_cfg<T, M_, N_, WM_, WN_>(a, stream);
     VT_CFG(128, 128, 2, 2)
@@ -408,7 +414,7 @@ int dispatch(const ConvArgs& a, int hint, vt_stream stream) {
 
 }  // namespace
 
-extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
+static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     VT_REQUIRE(d, "vt_conv2d: null descriptor");
     VT_REQUIRE(d->src0 && d->weight && d->out, "vt_conv2d: null tensor");
     VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv2d: dtype must be fp32 or bf16");
@@ -433,7 +439,6 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
                    (int64_t)d->n * d->out_h * d->out_w * (d->phases == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "vt_conv2d: tensor too large for 32-bit pixel indices");
 
-    ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src0 = d->src0;
     a.src1 = d->src1;
@@ -477,8 +482,23 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
     a.vec_store = (d->out_layout == VT_OUT_NHWC) && ((uintptr_t)d->out % 16 == 0) &&
                   ((int64_t)d->ld_out * osz % 16 == 0) && (d->cout % 8 == 0) &&
                   (!d->resid || (((uintptr_t)d->resid % 16 == 0) && ((int64_t)d->ld_res * osz % 16 == 0)));
+    return VT_OK;
+}
+
+extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
+    ConvArgs a;
+    const int rc = fill_args(d, a);
+    if (rc != VT_OK) return rc;
     if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, stream);
     return dispatch<float>(a, d->tile_hint, stream);
+}
+
+extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
+    ConvArgs a;
+    if (fill_args(d, a) != VT_OK) return -1;
+    int bm = 0, bn = 0;
+    choose_tile(a, d->tile_hint, bm, bn);
+    return bm * 1000 + bn;
 }
 
 // ---------------------------------------------------------------------------------

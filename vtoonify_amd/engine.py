@@ -48,8 +48,7 @@ class _Plan:
         self.gen_ops: List[Tuple] = []
         self.keep: list = []          # ctypes objects that must outlive the plan
         self.masks: List[torch.Tensor] = []
-        self.graph = None
-        self.graph_out = None
+        self.graphs: dict = {}        # with_style -> torch.cuda.CUDAGraph
 
 
 class VToonifyEngine:
@@ -131,10 +130,29 @@ class VToonifyEngine:
         plan.bufs[name] = t
         return t
 
-    def _op_conv(self, ops, plan, **kw):
+    def _op_conv(self, ops, plan, ref_macs=None, **kw):
+        """Append one vt_conv2d launch.  The op's info records the kernel instance (tile) and
+        its ALGORITHMIC work: flops = 2 x the MACs of the reference contraction it replaces
+        (`ref_macs` overrides that for the fused conv_transpose2d+blur form, whose polyphase
+        filters do 4x the transposed conv's MACs), bytes = every operand read once + the
+        output written once."""
         d = K.make_conv_desc(dtype=self.dt, **kw)
         plan.keep.append(d)
-        ops.append((self.lib.vt_conv2d, (C.byref(d),), "conv"))
+        tile = self.lib.vt_conv2d_tile(C.byref(d))
+        if tile < 0:
+            raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
+        cin = d.c0 + d.c1
+        m = d.n * d.out_h * d.out_w
+        cout_t = d.cout * d.phases
+        macs = m * cout_t * d.kh * d.kw * cin if ref_macs is None else ref_macs
+        osz = 4 if d.out_dtype == K.VT_F32 else 2
+        nbytes = (d.n * d.h * d.w * cin * self.esz + cout_t * d.kh * d.kw * cin * self.esz +
+                  m * cout_t * osz * (2 if d.resid else 1))
+        tname = "bf16" if self.dt == K.VT_BF16 else "f32"
+        info = {"name": "conv", "kernel": f"conv_igemm<{tname},{tile // 1000}x{tile % 1000}>",
+                "flops": 2 * macs, "bytes": nbytes, "cin": cin, "cout": cout_t, "m": m,
+                "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
+        ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
     def _op_linear(self, ops, y, ld_y, x, ld_x, W, b, rows, w_scale=1.0, b_scale=1.0, act=ACT_NONE,
                    slope=0.2, gain=1.0):
@@ -144,11 +162,18 @@ class VToonifyEngine:
                      C.c_void_p(b.data_ptr() if b is not None else 0), rows, in_dim, out_dim,
                      float(w_scale), float(b_scale), act, float(slope), float(gain)), "linear"))
 
+    @staticmethod
+    def _info(what):
+        if isinstance(what, dict):
+            return what
+        return {"name": what, "kernel": what, "flops": 0, "bytes": 0}
+
     def _run(self, ops, stream):
         for fn, args, what in ops:
             rc = fn(*args, stream)
             if rc != 0:
-                raise _lib.VtError(f"{what} failed (code {rc}): {self.lib.vt_last_error().decode()}")
+                raise _lib.VtError(f"{self._info(what)['name']} failed (code {rc}): "
+                                   f"{self.lib.vt_last_error().decode()}")
 
     # ------------------------------------------------------------------ style path
     def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
@@ -300,7 +325,9 @@ class VToonifyEngine:
                     ops.append((lib.vt_instnorm_stats,
                                 (C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()), C.c_void_p(src.data_ptr()),
                                  cf, C.c_void_p(0), 0, B, hw, cf, C.c_void_p(gb.data_ptr()),
-                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt), "instnorm"))
+                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
+                                {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
+                                 "bytes": B * hw * cf * self.esz}))
                     cn = "conv" if nm == "norm" else "conv2"
                     if dst is not None:
                         self._op_conv(ops, plan, src0=src, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
@@ -342,12 +369,16 @@ class VToonifyEngine:
                     ops.append((lib.vt_instnorm_stats,
                                 (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
                                  C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
-                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt), "instnorm"))
+                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
+                                {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
+                                 "bytes": 2 * B * hw * co * self.esz}))
                     nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
                     ops.append((lib.vt_affine_apply,
                                 (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
                                  C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
-                                 B, hw, co, dt), "affine"))
+                                 B, hw, co, dt),
+                                {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                 "bytes": 4 * B * hw * co * self.esz}))
                     mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
                     self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
                                   weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
@@ -357,7 +388,9 @@ class VToonifyEngine:
                 ops.append((lib.vt_fusion_pack,
                             (C.c_void_p(fem.data_ptr()), co + 8, C.c_void_p(f_e.data_ptr()), co,
                              C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
-                             B, hw, co, dt), "fusion_pack"))
+                             B, hw, co, dt),
+                            {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0,
+                             "bytes": B * hw * (co * self.esz + (co + 8) * self.esz + 16)}))
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
                 self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + 8 * self.esz, c1=co,
@@ -377,15 +410,19 @@ class VToonifyEngine:
             # skip = Upsample(skip): upfirdn2d up=2 pad=(2,1) (model.py:32-50), fp32 planes
             ops.append((lib.vt_upfirdn2d,
                         (C.c_void_p(rgb.data_ptr()), C.c_void_p(skip.data_ptr()), C.c_void_p(self.fir_rgb.data_ptr()),
-                         B * 3, h, w, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, K.VT_F32), "upfirdn2d"))
+                         B * 3, h, w, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, K.VT_F32),
+                        {"name": "upfirdn2d", "kernel": "upfirdn2d_tile<f32,up2>", "flops": 0,
+                         "bytes": B * 3 * hw * 5 * 4}))
             groups = [(0, B)] if ns == 1 else [(b, 1) for b in range(B)]
             for b0, nb in groups:
                 sidx = 0 if ns == 1 else b0
                 wm1 = plan.modw[n1][sidx]
                 wm2 = plan.modw[n2][sidx]
                 wm3 = plan.modw[n3][sidx]
-                # StyledConv(upsample): polyphase 3x3 with 4*Cout filters + pixel shuffle
-                self._op_conv(ops, plan, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co, ld0=co, n=nb, h=h,
+                # StyledConv(upsample): polyphase 3x3 with 4*Cout filters + pixel shuffle.
+                # Algorithmic MACs = the reference's conv_transpose2d (9 per in-pixel) + 4x4 blur
+                # (16 per out element), not the 36 per in-pixel the polyphase form spends.
+                self._op_conv(ops, plan, ref_macs=nb * hw * co * c1o * 9 + nb * 4 * hw * c1o * 16, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co, ld0=co, n=nb, h=h,
                               w=w, out_h=h, out_w=w, weight=wm1, cout=c1o, kh=3, kw=3, pad=1, phases=4,
                               bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
                               out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
@@ -453,33 +490,92 @@ class VToonifyEngine:
             self._plans[key] = plan
         if cin != plan.cin0:
             raise _lib.VtError(f"expected {plan.cin0} input channels, got {cin}")
-        stream = self._stream()
         # ---- per-call inputs into the plan's static buffers ---------------------------
         srows = style[:1] if shared_style else style
         skey = (id(plan), srows.data_ptr(), getattr(srows, "_version", 0), d_s, wspace)
         need_style = not (self.cache_styles and skey == self._style_key)
-        xs = x.detach().contiguous()
-        rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(plan.bufs["x_nhwc"].data_ptr()), plan.bufs["x_nhwc"].shape[-1],
-                                      C.c_void_p(xs.data_ptr()), B, cin, H * W, K.dt_code(xs.dtype), self.dt, stream)
-        _lib.check(rc, "vt_nchw_to_nhwc")
+        if "x_in" not in plan.bufs:
+            self._buf(plan, "x_in", (B, cin, H, W), torch.float32)
+        plan.bufs["x_in"].copy_(x.detach())
         if need_style:
             plan.bufs["style_in"].copy_(srows)
             plan.bufs["d_s"].fill_(d_s)
-            if self.dual and wspace:
-                # W-space input: resstyles = generator.style(style) per row is identical for
-                # all 18 rows, which the W+ path reproduces because every row equals `style`.
-                pass
-            self._run(plan.style_ops, stream)
             self._style_key = skey if self.cache_styles else None
-        self._run(plan.enc_ops, stream)
+        if use_graph and self.device.type == "cuda" and not return_feat:
+            self._replay(plan, need_style)
+        else:
+            self._launch(plan, need_style, not return_feat)
         if return_feat:
             feat, cf, h, w = plan.feat
             f = K.nhwc_to_nchw(feat, cf, B, cf, h, w, self.dtype, torch.float32, self.device, feat)
             return f, plan.skip_enc.clone()
-        self._run(plan.gen_ops, stream)
         image = plan.image.clone()
         if return_mask and self.dual:
             return image, [m.clone() for m in plan.masks]
         return image
+
+    def _launch(self, plan: _Plan, with_style: bool, with_gen: bool = True):
+        """Issue the plan's kernels on the current stream (eager or under graph capture)."""
+        stream = self._stream()
+        xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
+        B, cin, H, W = xin.shape
+        rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()), B, cin,
+                                      H * W, K.VT_F32, self.dt, stream)
+        _lib.check(rc, "vt_nchw_to_nhwc")
+        if with_style:
+            self._run(plan.style_ops, stream)
+        self._run(plan.enc_ops, stream)
+        if with_gen:
+            self._run(plan.gen_ops, stream)
+
+    def _replay(self, plan: _Plan, with_style: bool):
+        """hipGraph replay of the whole frame: ~140 kernel launches become one graph launch
+        (SURVEY.md section 7 step 9).  One graph per (plan, style path on/off); the plan's buffers
+        are static, so replay is just `x_in`/`style_in`/`d_s` refreshed + hipGraphLaunch."""
+        g = plan.graphs.get(with_style)
+        if g is None:
+            self._launch(plan, with_style)  # warm-up outside capture (module load, first-use init)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch(plan, with_style)
+            plan.graphs[with_style] = g
+        g.replay()
+
+    # ------------------------------------------------------------------ measurement hooks
+    def plan_for(self, B: int, H: int, W: int, shared_style: bool = True, has_res: bool = True) -> _Plan:
+        return self._plans[(B, H, W, bool(shared_style), bool(has_res and self.dual))]
+
+    def frame_ops(self, plan: _Plan, with_style: bool = True):
+        """Every launch of one frame, in order, as (fn, args, info) -- for per-kernel timing."""
+        return (list(plan.style_ops) if with_style else []) + list(plan.enc_ops) + list(plan.gen_ops)
+
+    def time_ops(self, plan: _Plan, iters: int = 5, with_style: bool = True):
+        """Per-launch durations from HIP events recorded on the launch stream around every
+        kernel of the frame (the whole frame runs `iters` times; durations are averaged).
+        Returns [(info, mean_ms)] in launch order.  GPU only."""
+        ops = self.frame_ops(plan, with_style)
+        stream = self._stream()
+        n = len(ops)
+        acc = [0.0] * n
+        for _ in range(iters):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            self._launch_input_only(plan, stream)
+            ev[0].record()
+            for i, (fn, args, what) in enumerate(ops):
+                rc = fn(*args, stream)
+                if rc != 0:
+                    raise _lib.VtError(f"{self._info(what)['name']} failed: {self.lib.vt_last_error().decode()}")
+                ev[i + 1].record()
+            torch.cuda.synchronize(self.device)
+            for i in range(n):
+                acc[i] += ev[i].elapsed_time(ev[i + 1])
+        return [(self._info(ops[i][2]), acc[i] / iters) for i in range(n)]
+
+    def _launch_input_only(self, plan: _Plan, stream):
+        xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
+        B, cin, H, W = xin.shape
+        _lib.check(self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()),
+                                            B, cin, H * W, K.VT_F32, self.dt, stream), "vt_nchw_to_nhwc")
 
     __call__ = forward
