@@ -123,13 +123,20 @@ typedef struct vt_conv_desc {
     int32_t out_layout;    /* VT_OUT_NHWC / VT_OUT_NCHW */
     int32_t out_dtype;     /* VT_F32 / VT_BF16 (NCHW output is always fp32) */
     int32_t dtype;         /* VT_F32 / VT_BF16: dtype of src*, weight */
-    int32_t tile_hint;     /* 0 = auto; otherwise BM*1000+BN of a compiled tile */
+    int32_t tile_hint;     /* 0 = auto; otherwise SPLITK*1000000 + BM*1000 + BN of a compiled tile
+                              (SPLITK 0 = auto) */
+    void* splitk_ws;       /* optional fp32 workspace for split-K (NULL: never split).  Small-M /  */
+    int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
+                              as separate workgroups and are summed in slice order by a second
+                              kernel; vt_conv2d_ws_bytes() says how much the heuristic wants */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
-/* The workgroup tile vt_conv2d would run `desc` on, as BM*1000+BN (-1: invalid descriptor).
+/* The workgroup tile vt_conv2d would run `desc` on, as SPLITK*1000000+BM*1000+BN (-1: invalid descriptor).
  * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
 int vt_conv2d_tile(const vt_conv_desc* desc);
+/* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */
+int64_t vt_conv2d_ws_bytes(const vt_conv_desc* desc);
 
 /* Plain conv weight (cout, cin_src, kh, kw) fp32 -> packed [cout][kh*kw][cin_dst],
  * multiplied by `scale` (EqualConv2d's 1/sqrt(fan_in), model/stylegan/model.py:101,117).

@@ -44,6 +44,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int32),
         ("out_layout", C.c_int32), ("out_dtype", C.c_int32), ("dtype", C.c_int32),
         ("tile_hint", C.c_int32),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -58,6 +59,7 @@ _SIGS = {
                                                        C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "vt_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "vt_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)]),
+    "vt_conv2d_ws_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "vt_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "vt_modulate_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -88,6 +90,11 @@ _lib_path = None
 
 
 def _bind(path: str):
+    # PyTorch-ROCm ships its own libamdhip64; load it FIRST so that this library's HIP calls bind
+    # to the runtime that owns torch's device context and streams.  (Loading ours first pulls
+    # /opt/rocm's copy into the process and the two runtimes do not see each other's devices:
+    # "no ROCm-capable device is detected" at the first launch.)
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -56,6 +56,10 @@ struct ConvArgs {
     float slope, gain_alpha, beta;
     int ld_res, ld_out, out_layout, out_f32, vec_store;
     int M, tiles_n;
+    // split-K: each tile's K range is cut into `splitk` slices of `kps` K-steps; slice s
+    // writes raw fp32 accumulators to partial[s][m][ldp] and conv_splitk_reduce finishes.
+    int splitk, kps, ldp;
+    float* partial;
 };
 
 template <typename T>
@@ -102,6 +106,64 @@ __device__ __forceinline__ u128 affine16(u128 v, const float* sc, const float* s
     return pack16<T>(f);
 }
 
+
+// Finished values (bias/activation/gain applied) of 8 consecutive output columns n..n+7 of
+// GEMM row m -> NHWC store with the optional residual add and the polyphase pixel shuffle.
+__device__ __forceinline__ void store_nhwc8(const ConvArgs& p, int m, int n, float* f) {
+    const int HoWo = p.Ho * p.Wo;
+    int64_t opix = m;
+    int co = n;
+    if (p.phases > 1) {
+        const int ph = n / p.cout;
+        co = n - ph * p.cout;
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        opix = ((int64_t)img * (2 * p.Ho) + 2 * oy + (ph >> 1)) * (2 * p.Wo) + 2 * ox + (ph & 1);
+    }
+    const int lim = (p.phases > 1) ? p.cout : p.coutT;
+    const int nvalid = (lim - co) < 8 ? (lim - co) : 8;
+    if (p.out_f32) {
+        float* o = (float*)p.out + opix * p.ld_out + co;
+        const float* rs = p.resid ? (const float*)p.resid + opix * p.ld_res + co : nullptr;
+        if (p.vec_store && nvalid == 8) {
+            if (rs) {
+                float g[8];
+                unpack16<float>(ld128(rs), g);
+                unpack16<float>(ld128(rs + 4), g + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
+            }
+            st128(o, pack16<float>(f));
+            st128(o + 4, pack16<float>(f + 4));
+        } else {
+            for (int i = 0; i < nvalid; ++i) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
+        }
+    } else {
+        bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
+        const bf16_t* rs = p.resid ? (const bf16_t*)p.resid + opix * p.ld_res + co : nullptr;
+        if (p.vec_store && nvalid == 8) {
+            if (rs) {
+                float g[8];
+                unpack16<bf16_t>(ld128(rs), g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
+            }
+            st128(o, pack16<bf16_t>(f));
+        } else {
+            for (int i = 0; i < nvalid; ++i)
+                o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
+        }
+    }
+}
+
+__device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float bias, float ga) {
+    v += bias;
+    if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
+    else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
+    return v * ga;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs p) {
@@ -123,7 +185,7 @@ conv_igemm_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / p.splitk, split = blockIdx.x - tile * p.splitk;
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -146,11 +208,11 @@ conv_igemm_kernel(const ConvArgs p) {
         a_y[i] = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
         a_x[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
     }
-    int kc = j * VEC, tap = 0;
-    while (kc >= p.cin) {
-        kc -= p.cin;
-        ++tap;
-    }
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = split * p.kps;
+    const int kt1 = (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;
+    int tap = (kt0 * BK + j * VEC) / p.cin;
+    int kc = (kt0 * BK + j * VEC) - tap * p.cin;
 
     const T* src0 = (const T*)p.src0;
     const T* src1 = (const T*)p.src1;
@@ -231,7 +293,7 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = kt1 - kt0;
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     const int a_row0 = wm * (TM * 16) + l15, b_row0 = wn * (TN * 16) + l15;
 
@@ -262,6 +324,23 @@ conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
+    // ---- split-K: raw accumulators to the fp32 workspace, conv_splitk_reduce finishes ---
+    if (p.splitk > 1) {
+        float* part = p.partial + (int64_t)split * p.M * p.ldp;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wn * (TN * 16) + b * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (TM * 16) + a * 16 + q * 4 + r;
+                    if (m < p.M && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
+                }
+            }
+        return;
+    }
+
     // ---- epilogue -----------------------------------------------------------------
     float* stage = reinterpret_cast<float*>(smem);
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
@@ -275,12 +354,8 @@ conv_igemm_kernel(const ConvArgs p) {
             const int co = (p.phases > 1) ? n % p.cout : n;
             const float bv = (p.bias && n < p.coutT) ? p.bias[co] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[pass][b][r] + bv;
-                if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
-                else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
-                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = v * ga;
-            }
+            for (int r = 0; r < 4; ++r)
+                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = conv_finish(p, acc[pass][b][r], bv, ga);
         }
         __syncthreads();
         if (p.out_layout == VT_OUT_NHWC) {
@@ -297,50 +372,7 @@ conv_igemm_kernel(const ConvArgs p) {
                     unpack16<float>(lo, f);
                     unpack16<float>(hi, f + 4);
                 }
-                int64_t opix = m;
-                int co = n;
-                if (p.phases > 1) {
-                    const int ph = n / p.cout;
-                    co = n - ph * p.cout;
-                    const int img = m / HoWo;
-                    const int rem = m - img * HoWo;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    opix = ((int64_t)img * (2 * p.Ho) + 2 * oy + (ph >> 1)) * (2 * p.Wo) + 2 * ox + (ph & 1);
-                }
-                const int lim = (p.phases > 1) ? p.cout : p.coutT;
-                const int nvalid = (lim - co) < 8 ? (lim - co) : 8;
-                if (p.out_f32) {
-                    float* o = (float*)p.out + opix * p.ld_out + co;
-                    const float* rs = p.resid ? (const float*)p.resid + opix * p.ld_res + co : nullptr;
-                    if (p.vec_store && nvalid == 8) {
-                        if (rs) {
-                            float g[8];
-                            unpack16<float>(ld128(rs), g);
-                            unpack16<float>(ld128(rs + 4), g + 4);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
-                        }
-                        st128(o, pack16<float>(f));
-                        st128(o + 4, pack16<float>(f + 4));
-                    } else {
-                        for (int i = 0; i < nvalid; ++i) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
-                    }
-                } else {
-                    bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
-                    const bf16_t* rs = p.resid ? (const bf16_t*)p.resid + opix * p.ld_res + co : nullptr;
-                    if (p.vec_store && nvalid == 8) {
-                        if (rs) {
-                            float g[8];
-                            unpack16<bf16_t>(ld128(rs), g);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
-                        }
-                        st128(o, pack16<bf16_t>(f));
-                    } else {
-                        for (int i = 0; i < nvalid; ++i)
-                            o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
-                    }
-                }
+                store_nhwc8(p, m, n, f);
             }
         } else {
             // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
@@ -362,42 +394,135 @@ conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
+// Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
+// then the same bias / activation / gain / residual / layout epilogue as the fused kernel.
+// One thread per (GEMM row, 8 output columns).
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs p) {
+    const int nv = p.ldp / 8;
+    const int64_t total = (int64_t)p.M * nv;
+    const int64_t slab = (int64_t)p.M * p.ldp;
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    const int HoWo = p.Ho * p.Wo;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int m, v8;
+        if (p.out_layout == VT_OUT_NHWC) {
+            m = (int)(idx / nv);
+            v8 = (int)(idx - (int64_t)m * nv);
+        } else {  // planar output: lanes walk pixels
+            v8 = (int)(idx / p.M);
+            m = (int)(idx - (int64_t)v8 * p.M);
+        }
+        const int n = v8 * 8;
+        if (n >= p.coutT) continue;
+        const float* src = p.partial + (int64_t)m * p.ldp + n;
+        float f[8];
+        unpack16<float>(ld128(src), f);
+        unpack16<float>(ld128(src + 4), f + 4);
+        for (int s = 1; s < p.splitk; ++s) {
+            float g[8];
+            unpack16<float>(ld128(src + s * slab), g);
+            unpack16<float>(ld128(src + s * slab + 4), g + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int nn = n + i;
+            const int co = (p.phases > 1) ? nn % p.cout : nn;
+            const float bv = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
+            f[i] = conv_finish(p, f[i], bv, ga);
+        }
+        if (p.out_layout == VT_OUT_NHWC) {
+            store_nhwc8(p, m, n, f);
+        } else {
+            float* o = (float*)p.out;
+            const float* rs = (const float*)p.resid;
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            for (int i = 0; i < 8 && n + i < p.coutT; ++i) {
+                const int64_t off = ((int64_t)img * p.cout + n + i) * HoWo + rem;
+                o[off] = f[i] + (rs ? p.beta * rs[off] : 0.0f);
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvArgs& a, vt_stream stream) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
     args.tiles_n = vt_cdiv(a.coutT, BN);
-    const int64_t tiles = (int64_t)vt_cdiv(a.M, BM) * args.tiles_n;
+    const int nk = vt_cdiv(a.K, BK);
+    if (args.splitk > 1) {
+        args.kps = vt_cdiv(nk, args.splitk);
+        args.splitk = vt_cdiv(nk, args.kps);  // no empty slices
+    }
+    if (args.splitk <= 1) {
+        args.splitk = 1;
+        args.kps = nk;
+    }
+    const int64_t tiles = (int64_t)vt_cdiv(a.M, BM) * args.tiles_n * args.splitk;
     if (tiles >= ((int64_t)1 << 31)) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
     auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;
     VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
-    return vt_check_launch("vt_conv2d");
+    int rc = vt_check_launch("vt_conv2d");
+    if (rc != VT_OK || args.splitk == 1) return rc;
+    int64_t blocks = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), stream, args);
+    return vt_check_launch("vt_conv2d(split-K reduce)");
 }
 
 // Tile selection shared by vt_conv2d and vt_conv2d_tile (bench / profiling use the latter to
 // name the kernel instance a descriptor runs on).
-static void choose_tile(const ConvArgs& a, int hint, int& bm, int& bn) {
+// Every choice below is a function of the PER-IMAGE geometry (Ho*Wo, cout, K) only -- never of
+// the batch -- so each output element sees the same K-chunking whether its frame is processed
+// alone or in a batch (bit-identical results; tests/test_engine.py).
+static void choose_tile(const ConvArgs& a, int hint, int ws_floats_avail, int bk, int& bm, int& bn, int& splitk) {
+    const int m1 = a.Ho * a.Wo;  // rows of one image
+    auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(m1, m) * vt_cdiv(a.coutT, n); };
     if (hint > 0) {
-        bm = hint / 1000;
+        bm = (hint / 1000) % 1000;
         bn = hint % 1000;
-        return;
+        splitk = hint / 1000000;
+    } else {
+        bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
+        bm = 128;
+        // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
+        if (bn == 128 && tiles(128, 128) < 512) bn = 64;
+        if (bn >= 64 && tiles(bm, bn) < 512) bm = 64;
+        splitk = 0;
     }
-    bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
-    bm = 128;
-    // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
-    auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(a.M, m) * vt_cdiv(a.coutT, n); };
-    if (bn == 128 && tiles(128, 128) < 512) bn = 64;
-    if (tiles(bm, bn) < 512) bm = 64;
-    if (bn == 64 && tiles(bm, bn) < 256 && bm == 64) bm = 32;
-    if (bn == 16 || bn == 32) bm = 128;
+    const int nk = vt_cdiv(a.K, bk);
+    if (splitk == 0) {
+        // too few tiles to fill 256 CUs: cut K so that ~768 workgroups exist, >= 2 K-steps each
+        splitk = 1;
+        const int64_t t = tiles(bm, bn);
+        if (t < 384 && nk >= 4) {
+            int64_t s = (768 + t - 1) / t;
+            if (s > nk / 2) s = nk / 2;
+            if (s > 32) s = 32;
+            splitk = (int)s;
+        }
+    }
+    if (splitk > 1) {
+        const int64_t need = (int64_t)splitk * a.M * ((a.coutT + 7) / 8 * 8);
+        if (!a.partial || need > ws_floats_avail) splitk = 1;  // no workspace: single pass
+    }
+    if (splitk < 1) splitk = 1;
 }
 
 template <typename T>
-int dispatch(const ConvArgs& a, int hint, vt_stream stream) {
-    int bm = 0, bn = 0;
-    choose_tile(a, hint, bm, bn);
+int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) {
+    int bm = 0, bn = 0, sk = 1;
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    choose_tile(a0, hint, (int)(ws_floats > 0x7fffffff ? 0x7fffffff : ws_floats), BK, bm, bn, sk);
+    ConvArgs a = a0;
+    a.splitk = sk;
+    a.ldp = (a.coutT + 7) / 8 * 8;
 #define VT_CFG(M_, N_, WM_, WN_) \
     if (bm == M_ && bn == N_) return launch_cfg<T, M_, N_, WM_, WN_>(a, stream);
     VT_CFG(128, 128, 2, 2)
@@ -479,6 +604,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.out_f32 = d->out_dtype == VT_F32;
     a.M = d->n * d->out_h * d->out_w;
     const int osz = a.out_f32 ? 4 : 2;
+    a.partial = (float*)d->splitk_ws;
     a.vec_store = (d->out_layout == VT_OUT_NHWC) && ((uintptr_t)d->out % 16 == 0) &&
                   ((int64_t)d->ld_out * osz % 16 == 0) && (d->cout % 8 == 0) &&
                   (!d->resid || (((uintptr_t)d->resid % 16 == 0) && ((int64_t)d->ld_res * osz % 16 == 0)));
@@ -489,16 +615,31 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
     ConvArgs a;
     const int rc = fill_args(d, a);
     if (rc != VT_OK) return rc;
-    if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, stream);
-    return dispatch<float>(a, d->tile_hint, stream);
+    const int64_t wsf = d->splitk_ws ? d->splitk_ws_bytes / 4 : 0;
+    if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, wsf, stream);
+    return dispatch<float>(a, d->tile_hint, wsf, stream);
 }
 
 extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    int bm = 0, bn = 0;
-    choose_tile(a, d->tile_hint, bm, bn);
-    return bm * 1000 + bn;
+    int bm = 0, bn = 0, sk = 1;
+    const int bk = d->dtype == VT_BF16 ? 64 : 32;
+    const int64_t wsf = d->splitk_ws ? d->splitk_ws_bytes / 4 : 0;
+    choose_tile(a, d->tile_hint, (int)(wsf > 0x7fffffff ? 0x7fffffff : wsf), bk, bm, bn, sk);
+    return sk * 1000000 + bm * 1000 + bn;
+}
+
+extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
+    ConvArgs a;
+    if (fill_args(d, a) != VT_OK) return -1;
+    int bm = 0, bn = 0, sk = 1;
+    const int bk = d->dtype == VT_BF16 ? 64 : 32;
+    float dummy;
+    a.partial = &dummy;  // "a workspace of any size exists": report what the heuristic would use
+    choose_tile(a, d->tile_hint, 0x7fffffff, bk, bm, bn, sk);
+    if (sk <= 1) return 0;
+    return (int64_t)sk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
 }
 
 // ---------------------------------------------------------------------------------

@@ -20,13 +20,15 @@ struct StatRec {
     float x0, s1, s2;
 };
 
-// chunk geometry shared by host and device
-__host__ __device__ inline int stat_chunk_pixels(int n, int hw) {
-    // aim for >= ~512 workgroups, 64..1024 pixels each
-    int64_t px = ((int64_t)n * hw) / 512;
+// chunk geometry shared by host and device.  It depends on the plane size ONLY (never on the
+// batch), so a frame's statistics -- hence its output bits -- are the same whether it is
+// processed alone or inside a batch.
+__host__ __device__ inline int stat_chunk_pixels(int hw) {
+    // ~256 chunks per image, 64..4096 pixels each
+    int px = (hw + 255) / 256;
     if (px < 64) px = 64;
-    if (px > 1024) px = 1024;
-    return (int)px;
+    if (px > 4096) px = 4096;
+    return px;
 }
 
 template <typename T>
@@ -114,28 +116,53 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
     }
 }
 
+// Merge the chunk records of 16 channels per workgroup: 16 chunk-lanes fold every 16th chunk
+// in order (Chan's update, fp64), then a fixed 4-level tree in LDS combines the lanes.  The
+// order is a function of `chunks` only => deterministic and batch-independent.
+struct Moments {
+    double cnt, mean, m2;
+};
+__device__ __forceinline__ Moments merge_moments(const Moments a, const Moments b) {
+    if (b.cnt == 0.0) return a;
+    if (a.cnt == 0.0) return b;
+    Moments r;
+    const double delta = b.mean - a.mean;
+    r.cnt = a.cnt + b.cnt;
+    r.mean = a.mean + delta * b.cnt / r.cnt;
+    r.m2 = a.m2 + b.m2 + delta * delta * a.cnt * b.cnt / r.cnt;
+    return r;
+}
+
 __global__ void __launch_bounds__(256)
 instnorm_finalize_kernel(float* __restrict__ scale, float* __restrict__ shift,
                          const StatRec* __restrict__ part, int n, int hw, int ctot, int chunk_px,
                          int chunks, const float* __restrict__ style_gb, int ld_gb) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * ctot) return;
-    const int img = idx / ctot, ch = idx - img * ctot;
-    double cnt = 0.0, mean = 0.0, m2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
+    __shared__ Moments red[16][17];
+    const int chl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int groups = ctot / 16;  // ctot is a multiple of 8; host guarantees 16 here
+    const int img = blockIdx.x / groups, ch = (blockIdx.x % groups) * 16 + chl;
+    Moments acc;
+    acc.cnt = acc.mean = acc.m2 = 0.0;
+    for (int k = cl; k < chunks; k += 16) {
         const StatRec r = part[((int64_t)img * chunks + k) * ctot + ch];
         int npx = hw - k * chunk_px;
         if (npx > chunk_px) npx = chunk_px;
-        const double nb = (double)npx;
-        const double mb = (double)r.x0 + (double)r.s1 / nb;
-        const double m2b = (double)r.s2 - (double)r.s1 * (double)r.s1 / nb;
-        const double delta = mb - mean;
-        const double tot = cnt + nb;
-        mean += delta * nb / tot;
-        m2 += m2b + delta * delta * cnt * nb / tot;
-        cnt = tot;
+        Moments b;
+        b.cnt = (double)npx;
+        b.mean = (double)r.x0 + (double)r.s1 / b.cnt;
+        b.m2 = (double)r.s2 - (double)r.s1 * (double)r.s1 / b.cnt;
+        acc = merge_moments(acc, b);
     }
-    double var = m2 / cnt;  // biased, as F.instance_norm
+    red[cl][chl] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int step = 1; step < 16; step <<= 1) {
+        if ((cl & (2 * step - 1)) == 0) red[cl][chl] = merge_moments(red[cl][chl], red[cl + step][chl]);
+        __syncthreads();
+    }
+    if (cl != 0) return;
+    const Moments t = red[0][chl];
+    double var = t.m2 / t.cnt;  // biased, as F.instance_norm
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
     float gamma = 1.0f, beta = 0.0f;
@@ -143,8 +170,9 @@ instnorm_finalize_kernel(float* __restrict__ scale, float* __restrict__ shift,
         gamma = style_gb[(int64_t)img * ld_gb + ch];
         beta = style_gb[(int64_t)img * ld_gb + ctot + ch];
     }
+    const int idx = img * ctot + ch;
     scale[idx] = gamma * rstd;
-    shift[idx] = beta - gamma * rstd * (float)mean;
+    shift[idx] = beta - gamma * rstd * (float)t.mean;
 }
 
 template <typename T>
@@ -265,7 +293,7 @@ inline unsigned grid_for(int64_t total) {
 
 extern "C" int64_t vt_instnorm_ws_bytes(int n, int hw, int c_total) {
     if (n <= 0 || hw <= 0 || c_total <= 0) return 0;
-    const int cpx = stat_chunk_pixels(n, hw);
+    const int cpx = stat_chunk_pixels(hw);
     const int chunks = (hw + cpx - 1) / cpx;
     return (int64_t)n * chunks * c_total * (int64_t)sizeof(StatRec);
 }
@@ -275,9 +303,9 @@ extern "C" int vt_instnorm_stats(float* scale, float* shift, const void* x, int 
                                  const float* style_gb, int ld_gb, void* partials, int dtype,
                                  vt_stream stream) {
     VT_REQUIRE(scale && shift && x && partials, "vt_instnorm_stats: null tensor");
-    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_instnorm_stats: c must be a positive multiple of 8");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 16 == 0, "vt_instnorm_stats: c must be a positive multiple of 16");
     VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_stats: dtype");
-    const int cpx = stat_chunk_pixels(n, hw);
+    const int cpx = stat_chunk_pixels(hw);
     const int chunks = (hw + cpx - 1) / cpx;
     const int ctot = absdiff_other ? 2 * c : c;
     dim3 grid((unsigned)(n * chunks)), block(256);
@@ -292,7 +320,7 @@ extern "C" int vt_instnorm_stats(float* scale, float* shift, const void* x, int 
     }
     int rc = vt_check_launch("vt_instnorm_stats(partial)");
     if (rc) return rc;
-    VT_LAUNCH(instnorm_finalize_kernel, dim3((unsigned)((n * ctot + 255) / 256)), dim3(256), stream,
+    VT_LAUNCH(instnorm_finalize_kernel, dim3((unsigned)(n * (ctot / 16))), dim3(256), stream,
               scale, shift, (const StatRec*)partials, n, hw, ctot, cpx, chunks, style_gb, ld_gb);
     return vt_check_launch("vt_instnorm_stats(finalize)");
 }

@@ -49,6 +49,7 @@ class _Plan:
         self.keep: list = []          # ctypes objects that must outlive the plan
         self.masks: List[torch.Tensor] = []
         self.graphs: dict = {}        # with_style -> torch.cuda.CUDAGraph
+        self.convs: list = []         # (ConvDesc, info) of every conv launch
 
 
 class VToonifyEngine:
@@ -138,9 +139,6 @@ class VToonifyEngine:
         output written once."""
         d = K.make_conv_desc(dtype=self.dt, **kw)
         plan.keep.append(d)
-        tile = self.lib.vt_conv2d_tile(C.byref(d))
-        if tile < 0:
-            raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
         cin = d.c0 + d.c1
         m = d.n * d.out_h * d.out_w
         cout_t = d.cout * d.phases
@@ -148,10 +146,9 @@ class VToonifyEngine:
         osz = 4 if d.out_dtype == K.VT_F32 else 2
         nbytes = (d.n * d.h * d.w * cin * self.esz + cout_t * d.kh * d.kw * cin * self.esz +
                   m * cout_t * osz * (2 if d.resid else 1))
-        tname = "bf16" if self.dt == K.VT_BF16 else "f32"
-        info = {"name": "conv", "kernel": f"conv_igemm<{tname},{tile // 1000}x{tile % 1000}>",
-                "flops": 2 * macs, "bytes": nbytes, "cin": cin, "cout": cout_t, "m": m,
-                "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
+        info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
+                "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
+        plan.convs.append((d, info))
         ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
     def _op_linear(self, ops, y, ld_y, x, ld_x, W, b, rows, w_scale=1.0, b_scale=1.0, act=ACT_NONE,
@@ -438,7 +435,29 @@ class VToonifyEngine:
                               out_dtype=K.VT_F32)
             out, co, skip, h, w = o2, c1o, rgb, 2 * h, 2 * w
         plan.image = skip
+        self._finalize_convs(plan)
         return plan
+
+    def _finalize_convs(self, plan: _Plan):
+        """One split-K workspace shared by every conv of the plan (launches are serial on one
+        stream), then name the kernel instance each descriptor runs on."""
+        need = 0
+        for d, _ in plan.convs:
+            b = int(self.lib.vt_conv2d_ws_bytes(C.byref(d)))
+            if b < 0:
+                raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
+            need = max(need, b)
+        ws = self._buf(plan, "splitk_ws", (max(need, 16),), torch.uint8) if need else None
+        tname = "bf16" if self.dt == K.VT_BF16 else "f32"
+        for d, info in plan.convs:
+            if ws is not None:
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), need
+            tile = self.lib.vt_conv2d_tile(C.byref(d))
+            if tile < 0:
+                raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
+            sk, bm, bn = tile // 1000000, (tile // 1000) % 1000, tile % 1000
+            info["kernel"] = f"conv_igemm<{tname},{bm}x{bn}>" + (f"+splitk{sk}" if sk > 1 else "")
+            info["splitk"] = sk
 
     # ------------------------------------------------------------------ public API
     def _stream(self):
