@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Micro-benchmark of vt_conv2d on the conv shapes of one VToonify-D frame (22x256x256).
+
+    python tools/conv_bench.py [--dtype bf16] [--hint SPLITK*1e6+BM*1e3+BN] [--only SUBSTR] [--iters 20]
+
+Prints per-shape time, TFLOP/s (flops actually issued) and GB/s (operands once).  Used to
+tune tiles / split-K and as the target of `rocprofv3 --pmc` runs.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from vtoonify_amd import _lib, kernels as K  # noqa: E402
+
+# (name, h, w, cin, cout, k, stride, dil, phases, out_layout)
+SHAPES = [
+    ("enc0.0 22->32 @256", 256, 256, 24, 32, 3, 1, 1, 1, "nhwc"),
+    ("enc0.2 32->128 @256", 256, 256, 32, 128, 3, 1, 1, 1, "nhwc"),
+    ("enc1.0 128->256 s2", 256, 256, 128, 256, 3, 2, 1, 1, "nhwc"),
+    ("enc1.2 256->256 @128", 128, 128, 256, 256, 3, 1, 1, 1, "nhwc"),
+    ("enc2.0 256->512 s2", 128, 128, 256, 512, 3, 2, 1, 1, "nhwc"),
+    ("enc2.2 512->512 @64", 64, 64, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("enc3.0 512->512 s2", 64, 64, 512, 512, 3, 2, 1, 1, "nhwc"),
+    ("res 512->512 @32", 32, 32, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("modres 512->512 @32 dil4", 32, 32, 512, 512, 3, 1, 4, 1, "nhwc"),
+    ("fus0 1024->512 @32", 32, 32, 1024, 512, 3, 1, 1, 1, "nhwc"),
+    ("mask0 1024->1 @32", 32, 32, 1024, 1, 3, 1, 1, 1, "nchw"),
+    ("fskip0 520->3 @32", 32, 32, 520, 3, 3, 1, 1, 1, "nchw"),
+    ("up 512->512 @32->64", 32, 32, 512, 512, 3, 1, 1, 4, "nhwc"),
+    ("same 512 @64", 64, 64, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("rgb 512->3 @64", 64, 64, 512, 3, 1, 1, 1, 1, "nchw"),
+    ("fus1 1024->512 @64", 64, 64, 1024, 512, 3, 1, 1, 1, "nhwc"),
+    ("mask1 1024->1 @64", 64, 64, 1024, 1, 3, 1, 1, 1, "nchw"),
+    ("up 512->256 @64->128", 64, 64, 512, 256, 3, 1, 1, 4, "nhwc"),
+    ("same 256 @128", 128, 128, 256, 256, 3, 1, 1, 1, "nhwc"),
+    ("fus2 512->256 @128", 128, 128, 512, 256, 3, 1, 1, 1, "nhwc"),
+    ("mask2 512->1 @128", 128, 128, 512, 1, 3, 1, 1, 1, "nchw"),
+    ("up 256->128 @128->256", 128, 128, 256, 128, 3, 1, 1, 4, "nhwc"),
+    ("same 128 @256", 256, 256, 128, 128, 3, 1, 1, 1, "nhwc"),
+    ("fus3 256->128 @256", 256, 256, 256, 128, 3, 1, 1, 1, "nhwc"),
+    ("mask3 256->1 @256", 256, 256, 256, 1, 3, 1, 1, 1, "nchw"),
+    ("fskip3 136->3 @256", 256, 256, 136, 3, 3, 1, 1, 1, "nchw"),
+    ("up 128->64 @256->512", 256, 256, 128, 64, 3, 1, 1, 4, "nhwc"),
+    ("same 64 @512", 512, 512, 64, 64, 3, 1, 1, 1, "nhwc"),
+    ("rgb 64->3 @512", 512, 512, 64, 3, 1, 1, 1, 1, "nchw"),
+    ("up 64->32 @512->1024", 512, 512, 64, 32, 3, 1, 1, 4, "nhwc"),
+    ("same 32 @1024", 1024, 1024, 32, 32, 3, 1, 1, 1, "nhwc"),
+    ("rgb 32->3 @1024", 1024, 1024, 32, 3, 1, 1, 1, 1, "nchw"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--hint", type=int, default=0)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--nosplit", action="store_true")
+    args = ap.parse_args()
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    esz = 2 if dt == torch.bfloat16 else 4
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    lib = _lib.lib()
+    import ctypes as C
+    tot = 0.0
+    for name, h, w, cin, cout, k, stride, dil, phases, lay in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        n = args.batch
+        pad = dil * (k // 2)
+        ho, wo = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        x = torch.randn(n, h, w, cin, device=dev).to(dt)
+        wt = (torch.randn(phases * cout, k * k, cin, device=dev) / (k * k * cin) ** 0.5).to(dt)
+        bias = torch.randn(cout, device=dev)
+        if lay == "nhwc":
+            out = torch.empty(n, ho * (2 if phases == 4 else 1), wo * (2 if phases == 4 else 1), cout, device=dev, dtype=dt)
+            kw = dict(out=out, ld_out=cout)
+        else:
+            out = torch.empty(n, cout, ho, wo, device=dev, dtype=torch.float32)
+            kw = dict(out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32)
+        d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout,
+                             kh=k, kw=k, stride=stride, pad=pad, dil=dil, phases=phases, bias=bias,
+                             act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint, **kw)
+        if not args.nosplit:
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        tile = lib.vt_conv2d_tile(C.byref(d))
+        if tile < 0:
+            print(f"{name:<28} rejected: {lib.vt_last_error().decode()}")
+            continue
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            _lib.check(lib.vt_conv2d(C.byref(d), st), "conv")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            lib.vt_conv2d(C.byref(d), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / args.iters
+        m = n * ho * wo
+        flops = 2.0 * m * phases * cout * k * k * cin
+        nbytes = x.numel() * esz + wt.numel() * esz + out.numel() * out.element_size()
+        tot += us
+        print(f"{name:<28} tile {tile:>9d} M={m:8d} N={phases * cout:5d} K={k * k * cin:5d} {us:9.1f} us "
+              f"{flops / us / 1e6:8.1f} TF/s {nbytes / us / 1e3:8.1f} GB/s")
+    print(f"total {tot:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
