@@ -124,7 +124,8 @@ typedef struct vt_conv_desc {
     int32_t out_dtype;     /* VT_F32 / VT_BF16 (NCHW output is always fp32) */
     int32_t dtype;         /* VT_F32 / VT_BF16: dtype of src*, weight */
     int32_t tile_hint;     /* 0 = auto; otherwise SPLITK*1000000 + BM*1000 + BN of a compiled tile
-                              (SPLITK 0 = auto) */
+                              (SPLITK 0 = auto); +1000000000 forces the register-staged
+                              loader where the direct-to-LDS one would apply */
     void* splitk_ws;       /* optional fp32 workspace for split-K (NULL: never split).  Small-M /  */
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
                               as separate workgroups and are summed in slice order by a second

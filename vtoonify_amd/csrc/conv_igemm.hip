@@ -60,6 +60,7 @@ struct ConvArgs {
     // writes raw fp32 accumulators to partial[s][m][ldp] and conv_splitk_reduce finishes.
     int splitk, kps, ldp;
     float* partial;
+    int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
 };
 
 template <typename T>
@@ -162,6 +163,86 @@ __device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float b
     if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
     else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
     return v * ga;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
+                                              unsigned char* smem, int m0, int n0, int split) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int SROWS = WM * 16, SLD = BN + 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int HoWo = p.Ho * p.Wo;
+    // ---- split-K: raw accumulators to the fp32 workspace, conv_splitk_reduce finishes ---
+    if (p.splitk > 1) {
+        float* part = p.partial + (int64_t)split * p.M * p.ldp;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wn * (TN * 16) + b * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (TM * 16) + a * 16 + q * 4 + r;
+                    if (m < p.M && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
+                }
+            }
+        return;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------
+    float* stage = reinterpret_cast<float*>(smem);
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+#pragma unroll
+    for (int pass = 0; pass < TM; ++pass) {
+        if (pass > 0) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int colb = wn * (TN * 16) + b * 16;
+            const int n = n0 + colb + l15;
+            const int co = (p.phases > 1) ? n % p.cout : n;
+            const float bv = (p.bias && n < p.coutT) ? p.bias[co] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = conv_finish(p, acc[pass][b][r], bv, ga);
+        }
+        __syncthreads();
+        if (p.out_layout == VT_OUT_NHWC) {
+            constexpr int CV = BN / 8;
+            for (int idx = tid; idx < SROWS * CV; idx += 256) {
+                const int row_l = idx / CV, cv = idx - row_l * CV;
+                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int n = n0 + cv * 8;
+                if (m >= p.M || n >= p.coutT) continue;
+                float f[8];
+                {
+                    const u128 lo = ld128(stage + row_l * SLD + cv * 8);
+                    const u128 hi = ld128(stage + row_l * SLD + cv * 8 + 4);
+                    unpack16<float>(lo, f);
+                    unpack16<float>(hi, f + 4);
+                }
+                store_nhwc8(p, m, n, f);
+            }
+        } else {
+            // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
+            float* o = (float*)p.out;
+            const float* rs = (const float*)p.resid;
+            for (int idx = tid; idx < SROWS * BN; idx += 256) {
+                const int col = idx / SROWS, row_l = idx - col * SROWS;
+                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int n = n0 + col;
+                if (m >= p.M || n >= p.coutT) continue;
+                const int img = m / HoWo;
+                const int rem = m - img * HoWo;
+                const int64_t off = ((int64_t)img * p.cout + n) * HoWo + rem;
+                float v = stage[row_l * SLD + col];
+                if (rs) v += p.beta * rs[off];
+                o[off] = v;
+            }
+        }
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -324,74 +405,174 @@ conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- split-K: raw accumulators to the fp32 workspace, conv_splitk_reduce finishes ---
-    if (p.splitk > 1) {
-        float* part = p.partial + (int64_t)split * p.M * p.ldp;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + b * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (TM * 16) + a * 16 + q * 4 + r;
-                    if (m < p.M && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
-                }
-            }
-        return;
-    }
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, split);
+}
 
-    // ---- epilogue -----------------------------------------------------------------
-    float* stage = reinterpret_cast<float*>(smem);
-    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+// ---------------------------------------------------------------------------------------
+// Fast path: direct-to-LDS loader (buffer_load_dwordx4 ... lds).
+//
+// When every K-step lies inside ONE filter tap and ONE concat source (channel counts are
+// multiples of the K-step) the im2col gather needs no per-step vector arithmetic at all:
+//   address = buffer base (SGPR descriptor)
+//           + voffset  per-lane byte offset of the output pixel's "centre" input pixel and of
+//                      the lane's 16-byte chunk; replaced by an out-of-range sentinel when the
+//                      tap falls outside the image for that pixel -- the buffer unit then writes
+//                      ZEROS to LDS, which is exactly the conv's zero padding (probed on gfx950,
+//                      tools/probe/glds_probe.hip: soffset takes part in the range check)
+//           + soffset  wave-uniform byte offset of (tap, channel chunk)  (SGPR)
+// and the data lands in LDS without touching VGPRs.  One wave-instruction fills 8 tile rows of
+// 128 B (lane l -> row l/8, physical 16-byte slot l%8); the XOR swizzle of the register-staged
+// kernel is kept by permuting which chunk of its row a lane fetches: chunk (l%8) ^ (row&7).
+// Per K-step a wave issues (BM+BN)/32 loads, 2*(TM+TN) ds_read_b128 and 2*TM*TN MFMAs; the
+// validity masks / effective offsets are recomputed only when the tap (or source) changes.
+// Two LDS buffers: the loads of step t+1 are in flight during the MFMAs of step t.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t GLDS_OOB = 0x80000000u;  // >= any num_records we create (< 2^31)
+
+struct GldsArgs {
+    uint32_t nrec0, nrec1, nrecw;   // buffer sizes in bytes (incl. the tap bias for sources)
+    uint32_t bias0, bias1;          // bytes the source bases are moved back by ((pad*W+pad) pixels)
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VEC = 16 / ESZ;
+    constexpr int BK = 8 * VEC;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups per tile
+    constexpr int AI = (GA + 3) / 4, BI = (GB + 3) / 4;  // groups per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int SROWS = WM * 16, SLD = BN + 4;
+    static_assert(SROWS * SLD * 4 <= 2 * (A_BYTES + B_BYTES), "epilogue staging must fit");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    auto sA = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES); };
+    auto sB = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & 3;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = blockIdx.x / p.splitk, split = blockIdx.x - tile * p.splitk;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- loader state ---------------------------------------------------------------
+    const int lrow = lane >> 3;                  // row inside an 8-row group
+    const int jj = (lane & 7) ^ lrow;            // logical 16-byte chunk this lane fetches
+    uint32_t ctr0[AI], ctr1[AI], eff[AI];
+    int cy[AI], cx[AI];
 #pragma unroll
-    for (int pass = 0; pass < TM; ++pass) {
-        if (pass > 0) __syncthreads();
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int colb = wn * (TN * 16) + b * 16;
-            const int n = n0 + colb + l15;
-            const int co = (p.phases > 1) ? n % p.cout : n;
-            const float bv = (p.bias && n < p.coutT) ? p.bias[co] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = conv_finish(p, acc[pass][b][r], bv, ga);
-        }
-        __syncthreads();
-        if (p.out_layout == VT_OUT_NHWC) {
-            constexpr int CV = BN / 8;
-            for (int idx = tid; idx < SROWS * CV; idx += 256) {
-                const int row_l = idx / CV, cv = idx - row_l * CV;
-                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
-                const int n = n0 + cv * 8;
-                if (m >= p.M || n >= p.coutT) continue;
-                float f[8];
-                {
-                    const u128 lo = ld128(stage + row_l * SLD + cv * 8);
-                    const u128 hi = ld128(stage + row_l * SLD + cv * 8 + 4);
-                    unpack16<float>(lo, f);
-                    unpack16<float>(hi, f + 4);
-                }
-                store_nhwc8(p, m, n, f);
-            }
-        } else {
-            // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
-            float* o = (float*)p.out;
-            const float* rs = (const float*)p.resid;
-            for (int idx = tid; idx < SROWS * BN; idx += 256) {
-                const int col = idx / SROWS, row_l = idx - col * SROWS;
-                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
-                const int n = n0 + col;
-                if (m >= p.M || n >= p.coutT) continue;
-                const int img = m / HoWo;
-                const int rem = m - img * HoWo;
-                const int64_t off = ((int64_t)img * p.cout + n) * HoWo + rem;
-                float v = stage[row_l * SLD + col];
-                if (rs) v += p.beta * rs[off];
-                o[off] = v;
-            }
-        }
+    for (int i = 0; i < AI; ++i) {
+        const int grp = i * 4 + wave;
+        const int m = m0 + grp * 8 + lrow;
+        const bool ok = grp < GA && m < p.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / HoWo;
+        const int rem = mm - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const uint32_t pix = (uint32_t)((img * p.H + oy * p.stride) * p.W + ox * p.stride);
+        ctr0[i] = pix * (uint32_t)(p.ld0 * ESZ) + jj * 16;
+        ctr1[i] = pix * (uint32_t)(p.ld1 * ESZ) + jj * 16;
+        cy[i] = ok ? oy * p.stride - p.pad : -0x40000000;  // never valid
+        cx[i] = ox * p.stride - p.pad;
+        eff[i] = GLDS_OOB;
     }
+    uint32_t woff[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int grp = i * 4 + wave;
+        const int n = n0 + grp * 8 + lrow;
+        woff[i] = (grp < GB && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    const BufRsrc r0 = vt_make_rsrc((const char*)p.src0 - g.bias0, g.nrec0);
+    const BufRsrc r1 = vt_make_rsrc(p.src1 ? (const char*)p.src1 - g.bias1 : (const char*)p.src0, p.src1 ? g.nrec1 : 0u);
+    const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
+
+    // K-step state (all wave-uniform)
+    const int nk_all = p.K / BK;
+    const int kt0 = split * p.kps;
+    const int kt1 = (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;
+    int tap = (kt0 * BK) / p.cin;
+    int kc = kt0 * BK - tap * p.cin;   // channel offset inside the concatenated input
+    int seg_tap = -1, seg_src = -1;
+    uint32_t soff_a = 0;               // byte offset of (tap, first channel of the source)
+
+    auto issue = [&](int kt, int buf) {
+        const int src = (kc >= p.c0) ? 1 : 0;
+        if (tap != seg_tap || src != seg_src) {   // uniform: new tap or new source
+            seg_tap = tap;
+            seg_src = src;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int dy = ky * p.dil, dx = kx * p.dil;
+            soff_a = (uint32_t)(dy * p.W + dx) * (uint32_t)((src ? p.ld1 : p.ld0) * ESZ);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const bool in = (unsigned)(cy[i] + dy) < (unsigned)p.H && (unsigned)(cx[i] + dx) < (unsigned)p.W;
+                eff[i] = in ? (src ? ctr1[i] : ctr0[i]) : GLDS_OOB;
+            }
+        }
+        const uint32_t sa = soff_a + (uint32_t)((src ? kc - p.c0 : kc) * ESZ);
+        const BufRsrc& ra = src ? r1 : r0;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int grp = i * 4 + wave;
+            if (GA % 4 == 0 || grp < GA) vt_glds16(ra, sA(buf) + grp * 1024, eff[i], sa);
+        }
+        const uint32_t sw = (uint32_t)(kt * BK * ESZ);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int grp = i * 4 + wave;
+            if (GB % 4 == 0 || grp < GB) vt_glds16(rw, sB(buf) + grp * 1024, woff[i], sw);
+        }
+    };
+    auto advance = [&]() {
+        kc += BK;
+        if (kc >= p.cin) {
+            kc = 0;
+            ++tap;
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
+    const int a_row0 = wm * (TM * 16) + l15, b_row0 = wn * (TN * 16) + l15;
+
+    issue(kt0, 0);
+    vt_glds_wait();
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            advance();
+            issue(kt + 1, buf ^ 1);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int phys = ((sub * 4 + q) ^ l7) << 4;
+            u128 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = ld128(sA(buf) + (a_row0 + a * 16) * 128 + phys);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = ld128(sB(buf) + (b_row0 + b * 16) * 128 + phys);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+        }
+        vt_glds_wait();
+        __syncthreads();
+    }
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, split);
 }
 
 // Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
@@ -447,6 +628,31 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
     }
 }
 
+// The direct-to-LDS loader applies when every K-step stays inside one tap and one source and
+// all byte offsets fit the 31-bit buffer range; everything else runs the register-staged kernel.
+template <typename T>
+static bool glds_eligible(const ConvArgs& a, GldsArgs& g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BK = 8 * (16 / ESZ);
+    if (a.force_generic || a.transposed || a.in_scale) return false;
+    if (a.c0 % BK != 0 || a.c1 % BK != 0) return false;
+    const int64_t lim = ((int64_t)1 << 31) - 4096;
+    const int64_t px = (int64_t)a.N * a.H * a.W;
+    const int64_t b0 = ((int64_t)a.pad * a.W + a.pad) * a.ld0 * ESZ;
+    const int64_t b1 = ((int64_t)a.pad * a.W + a.pad) * a.ld1 * ESZ;
+    const int64_t n0 = px * a.ld0 * ESZ + b0, n1 = px * a.ld1 * ESZ + b1;
+    const int64_t nw = (int64_t)a.coutT * a.K * ESZ;
+    // largest soffset: last tap + all channels
+    const int64_t tapmax = ((int64_t)(a.taps / a.kw - 1) * a.dil * a.W + (int64_t)(a.kw - 1) * a.dil);
+    if (n0 + tapmax * a.ld0 * ESZ >= lim || n1 + tapmax * a.ld1 * ESZ >= lim || nw >= lim) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrec1 = (uint32_t)n1;
+    g.nrecw = (uint32_t)nw;
+    g.bias0 = (uint32_t)b0;
+    g.bias1 = (uint32_t)b1;
+    return true;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvArgs& a, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -466,8 +672,14 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;
-    VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
+    GldsArgs g;
+    if (glds_eligible<T>(args, g)) {
+        auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN>;
+        VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+    } else {
+        auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;
+        VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
+    }
     int rc = vt_check_launch("vt_conv2d");
     if (rc != VT_OK || args.splitk == 1) return rc;
     int64_t blocks = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
@@ -484,6 +696,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 static void choose_tile(const ConvArgs& a, int hint, int ws_floats_avail, int bk, int& bm, int& bn, int& splitk) {
     const int m1 = a.Ho * a.Wo;  // rows of one image
     auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(m1, m) * vt_cdiv(a.coutT, n); };
+    hint %= 1000000000;  // +1e9 = "register-staged kernel" flag, handled by dispatch()
     if (hint > 0) {
         bm = (hint / 1000) % 1000;
         bn = hint % 1000;
@@ -521,6 +734,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     choose_tile(a0, hint, (int)(ws_floats > 0x7fffffff ? 0x7fffffff : ws_floats), BK, bm, bn, sk);
     ConvArgs a = a0;
+    a.force_generic = hint >= 1000000000;
     a.splitk = sk;
     a.ldp = (a.coutT + 7) / 8 * 8;
 #define VT_CFG(M_, N_, WM_, WN_) \

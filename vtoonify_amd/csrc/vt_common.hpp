@@ -172,6 +172,46 @@ __device__ __forceinline__ u128 pack16<bf16_t>(const float* f) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------
+// buffer descriptor + direct-to-LDS 16-byte load (buffer_load_dwordx4 ... offen lds)
+//   every lane fetches 16 bytes at base + voff + soff and the wave writes them lane-linear
+//   to lds_wave_base + lane*16; bytes at or beyond `nrec` read as ZERO (range check is on
+//   voff + soff).  The emulation build reproduces exactly that.
+// ---------------------------------------------------------------------------------
+#ifdef VT_EMU
+struct BufRsrc {
+    const char* base;
+    uint32_t nrec;
+};
+static inline BufRsrc vt_make_rsrc(const void* base, uint32_t nrec) { return BufRsrc{(const char*)base, nrec}; }
+static inline void vt_glds16(const BufRsrc& r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    unsigned char* dst = (unsigned char*)lds_wave_base + (size_t)emu::cur()->lane * 16;
+    const uint64_t off = (uint64_t)voff + soff;
+    for (int d = 0; d < 4; ++d) {
+        if (off + 4 * d + 4 <= r.nrec) memcpy(dst + 4 * d, r.base + off + 4 * d, 4);
+        else memset(dst + 4 * d, 0, 4);
+    }
+}
+static inline void vt_glds_wait() {}
+static inline int vt_uniform(int v) { return v; }
+#else
+struct BufRsrc {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ BufRsrc vt_make_rsrc(const void* base, uint32_t nrec) {
+    BufRsrc b;
+    // word3 0x00020000: raw buffer, 32-bit data format bits as used by the compiler's own buffer ops
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nrec, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ void vt_glds16(const BufRsrc& r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                             voff, soff, 0, 0);
+}
+__device__ __forceinline__ void vt_glds_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0), expcnt/lgkmcnt untouched */ }
+__device__ __forceinline__ int vt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 // wavefront (64 lanes) all-reduce sum via xor shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
