@@ -434,23 +434,27 @@ struct GldsArgs {
     uint32_t bias0, bias1;          // bytes the source bases are moved back by ((pad*W+pad) pixels)
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NST>
 __global__ void __launch_bounds__(256)
 conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    static_assert(NST >= 2 && NST <= 4, "2..4 LDS stages");
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VEC = 16 / ESZ;
     constexpr int BK = 8 * VEC;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups per tile
-    constexpr int AI = (GA + 3) / 4, BI = (GB + 3) / 4;  // groups per wave
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    // every wave issues the same number of loads per K-step (counted vmcnt below): tiles are
+    // padded to a multiple of 32 rows in LDS; rows beyond the tile fetch the zero sentinel
+    constexpr int AI = (BM + 31) / 32, BI = (BN + 31) / 32;
+    constexpr int LOADS = AI + BI;
+    constexpr int A_BYTES = AI * 32 * 128, B_BYTES = BI * 32 * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int SROWS = WM * 16, SLD = BN + 4;
-    static_assert(SROWS * SLD * 4 <= 2 * (A_BYTES + B_BYTES), "epilogue staging must fit");
+    static_assert(SROWS * SLD * 4 <= NST * STAGE, "epilogue staging must fit");
 
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-    auto sA = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES); };
-    auto sB = [&](int b) -> unsigned char* { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    auto sA = [&](int b) -> unsigned char* { return smem + b * STAGE; };
+    auto sB = [&](int b) -> unsigned char* { return smem + b * STAGE + A_BYTES; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -468,9 +472,9 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     int cy[AI], cx[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int grp = i * 4 + wave;
-        const int m = m0 + grp * 8 + lrow;
-        const bool ok = grp < GA && m < p.M;
+        const int row = (i * 4 + wave) * 8 + lrow;
+        const int m = m0 + row;
+        const bool ok = row < BM && m < p.M;
         const int mm = ok ? m : 0;
         const int img = mm / HoWo;
         const int rem = mm - img * HoWo;
@@ -485,15 +489,15 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     uint32_t woff[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int grp = i * 4 + wave;
-        const int n = n0 + grp * 8 + lrow;
-        woff[i] = (grp < GB && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+        const int row = (i * 4 + wave) * 8 + lrow;
+        const int n = n0 + row;
+        woff[i] = (row < BN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
     }
     const BufRsrc r0 = vt_make_rsrc((const char*)p.src0 - g.bias0, g.nrec0);
     const BufRsrc r1 = vt_make_rsrc(p.src1 ? (const char*)p.src1 - g.bias1 : (const char*)p.src0, p.src1 ? g.nrec1 : 0u);
     const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
 
-    // K-step state (all wave-uniform)
+    // K-step state (all wave-uniform); `tap`/`kc` describe the NEXT step to be issued
     const int nk_all = p.K / BK;
     const int kt0 = split * p.kps;
     const int kt1 = (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;
@@ -519,18 +523,11 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
         const uint32_t sa = soff_a + (uint32_t)((src ? kc - p.c0 : kc) * ESZ);
         const BufRsrc& ra = src ? r1 : r0;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int grp = i * 4 + wave;
-            if (GA % 4 == 0 || grp < GA) vt_glds16(ra, sA(buf) + grp * 1024, eff[i], sa);
-        }
+        for (int i = 0; i < AI; ++i) vt_glds16(ra, sA(buf) + (i * 4 + wave) * 1024, eff[i], sa);
         const uint32_t sw = (uint32_t)(kt * BK * ESZ);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int grp = i * 4 + wave;
-            if (GB % 4 == 0 || grp < GB) vt_glds16(rw, sB(buf) + grp * 1024, woff[i], sw);
-        }
-    };
-    auto advance = [&]() {
+        for (int i = 0; i < BI; ++i) vt_glds16(rw, sB(buf) + (i * 4 + wave) * 1024, woff[i], sw);
+        // advance to the following step
         kc += BK;
         if (kc >= p.cin) {
             kc = 0;
@@ -547,14 +544,29 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     const int a_row0 = wm * (TM * 16) + l15, b_row0 = wn * (TN * 16) + l15;
 
-    issue(kt0, 0);
-    vt_glds_wait();
-    __syncthreads();
+    // prologue: NST-1 steps in flight, the first one landed
+    int issued = kt0;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (issued < kt1) {
+            issue(issued, s);
+            ++issued;
+        }
+    // Outstanding loads allowed while step `kt` is consumed: those of the steps issued after it.
+    auto wait_for = [&](int kt) {
+        const int ahead = issued - 1 - kt;  // steps issued beyond kt
+        if (NST >= 4 && ahead >= 2) vt_glds_wait_n<2 * LOADS>();
+        else if (NST >= 3 && ahead >= 1) vt_glds_wait_n<LOADS>();
+        else vt_glds_wait_n<0>();
+    };
+    wait_for(kt0);
+    vt_lds_barrier();
+
+    int buf = 0, nbuf = NST - 1;  // buffer of step kt / buffer the next issued step goes to
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            advance();
-            issue(kt + 1, buf ^ 1);
+        if (issued < kt1) {
+            issue(issued, nbuf);
+            ++issued;
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -569,9 +581,14 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
         }
-        vt_glds_wait();
-        __syncthreads();
+        // step kt+1 must have landed (in every wave) before anyone reads it; step kt's buffer may
+        // be overwritten by the next issue once every wave has finished reading it
+        wait_for(kt + 1);
+        vt_lds_barrier();
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
     }
+    __syncthreads();
     conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, split);
 }
 
@@ -674,7 +691,11 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     }
     GldsArgs g;
     if (glds_eligible<T>(args, g)) {
-        auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN>;
+        // 3 LDS stages (2 K-steps of loads in flight); 4 when the tile is small enough that
+        // three workgroups still fit a CU's 160 KiB
+        constexpr int STAGE = ((BM + 31) / 32 + (BN + 31) / 32) * 32 * 128;
+        constexpr int NST = STAGE <= 12 * 1024 ? 4 : 3;
+        auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST>;
         VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
     } else {
         auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;

@@ -193,6 +193,9 @@ static inline void vt_glds16(const BufRsrc& r, void* lds_wave_base, uint32_t vof
     }
 }
 static inline void vt_glds_wait() {}
+template <int N>
+static inline void vt_glds_wait_n() {}
+static inline void vt_lds_barrier() { emu::syncthreads(); }
 static inline int vt_uniform(int v) { return v; }
 #else
 struct BufRsrc {
@@ -209,6 +212,19 @@ __device__ __forceinline__ void vt_glds16(const BufRsrc& r, void* lds_wave_base,
                                              voff, soff, 0, 0);
 }
 __device__ __forceinline__ void vt_glds_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0), expcnt/lgkmcnt untouched */ }
+// wait until at most N of this wave's vector-memory operations (LDS-DMA loads included) are
+// outstanding; expcnt / lgkmcnt untouched.  gfx9 encoding: vmcnt = simm16[15:14]:[3:0].
+template <int N>
+__device__ __forceinline__ void vt_glds_wait_n() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x0070 | 0x0f00 | ((N >> 4) << 14));
+}
+// workgroup barrier that does NOT drain in-flight LDS-DMA loads (a plain __syncthreads() waits
+// vmcnt(0)): LDS reads of this wave are retired first, vector memory is left to the counted waits
+__device__ __forceinline__ void vt_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 __device__ __forceinline__ int vt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
