@@ -166,6 +166,26 @@ int vt_linear(float* y, int ld_y, const float* x, int ld_x, const float* W, cons
               int rows, int in_dim, int out_dim, float w_scale, float b_scale, int act,
               float slope, float gain, vt_stream stream);
 
+/* Batched forms of vt_linear / vt_modulate_weight: `items` is a HOST array, copied by value
+ * into the launch (nothing to keep alive, hipGraph-capture safe).  All items of one call are
+ * independent (no item may read another item's output).  The style path of a frame is ~50
+ * GEMVs + 15 modulations; batching turns them into 5 launches. */
+typedef struct vt_linear_item {
+    float* y; const float* x; const float* W; const float* b; /* b may be NULL */
+    int32_t ld_y, ld_x, rows, in_dim, out_dim, act;
+    float w_scale, b_scale, slope, gain;
+} vt_linear_item;
+int vt_linear_batch(const vt_linear_item* items, int n_items, vt_stream stream);
+
+typedef struct vt_modulate_item {
+    void* out; const float* weight; const float* s; const float* fir; /* fir may be NULL */
+    int32_t cout, cin, k, demodulate;
+    float scale;
+    int32_t reserved;
+} vt_modulate_item;
+int vt_modulate_weight_batch(const vt_modulate_item* items, int n_items, int out_dtype,
+                             vt_stream stream);
+
 /* PixelNorm (model/stylegan/model.py:17-18) on (rows, dim) fp32. */
 int vt_pixel_norm(float* y, const float* x, int rows, int dim, vt_stream stream);
 

@@ -48,6 +48,19 @@ class ConvDesc(C.Structure):
     ]
 
 
+class LinearItem(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("W", C.c_void_p), ("b", C.c_void_p),
+                ("ld_y", C.c_int32), ("ld_x", C.c_int32), ("rows", C.c_int32), ("in_dim", C.c_int32),
+                ("out_dim", C.c_int32), ("act", C.c_int32),
+                ("w_scale", C.c_float), ("b_scale", C.c_float), ("slope", C.c_float), ("gain", C.c_float)]
+
+
+class ModulateItem(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("weight", C.c_void_p), ("s", C.c_void_p), ("fir", C.c_void_p),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("k", C.c_int32), ("demodulate", C.c_int32),
+                ("scale", C.c_float), ("reserved", C.c_int32)]
+
+
 _SIGS = {
     "vt_abi_version": (C.c_int, []),
     "vt_last_error": (C.c_char_p, []),
@@ -67,6 +80,8 @@ _SIGS = {
     "vt_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                             C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                             C.c_void_p]),
+    "vt_linear_batch": (C.c_int, [C.POINTER(LinearItem), C.c_int, C.c_void_p]),
+    "vt_modulate_weight_batch": (C.c_int, [C.POINTER(ModulateItem), C.c_int, C.c_int, C.c_void_p]),
     "vt_pixel_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vt_instnorm_ws_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "vt_instnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

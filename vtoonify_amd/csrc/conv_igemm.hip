@@ -691,10 +691,11 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     }
     GldsArgs g;
     if (glds_eligible<T>(args, g)) {
-        // 3 LDS stages (2 K-steps of loads in flight); 4 when the tile is small enough that
-        // three workgroups still fit a CU's 160 KiB
+        // As many LDS stages (K-steps of loads in flight) as still let TWO workgroups share a
+        // CU's 160 KiB: measured on MI355X, occupancy 2 with 2 stages beats occupancy 1 with 3
+        // (128x128: 2 stages; 128x64 / 64x128: 3; 64x64 and smaller: 4)
         constexpr int STAGE = ((BM + 31) / 32 + (BN + 31) / 32) * 32 * 128;
-        constexpr int NST = STAGE <= 12 * 1024 ? 4 : 3;
+        constexpr int NST = STAGE * 4 <= 80 * 1024 ? 4 : STAGE * 3 <= 80 * 1024 ? 3 : 2;
         auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST>;
         VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
     } else {
@@ -723,11 +724,19 @@ static void choose_tile(const ConvArgs& a, int hint, int ws_floats_avail, int bk
         bn = hint % 1000;
         splitk = hint / 1000000;
     } else {
+        // keep >= ~2 workgroups per CU (256 CUs) where the problem allows it; measured on the
+        // frame's shapes (tools/conv_bench.py): 128x128 when M is large, 64x128 for mid M with
+        // wide N, 64x64 for the 64x64 / 32x32-pixel layers
         bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
         bm = 128;
-        // keep >= ~2 workgroups per CU where the problem allows it (256 CUs)
-        if (bn == 128 && tiles(128, 128) < 512) bn = 64;
-        if (bn >= 64 && tiles(bm, bn) < 512) bm = 64;
+        if (bn == 128) {
+            if (tiles(128, 128) < 512) {
+                bm = 64;
+                if (tiles(64, 128) < 512 && tiles(64, 64) >= 128) bn = 64;
+            }
+        } else if (bn == 64) {
+            if (tiles(128, 64) < 512) bm = 64;
+        }
         splitk = 0;
     }
     const int nk = vt_cdiv(a.K, bk);

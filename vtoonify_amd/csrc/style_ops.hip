@@ -129,6 +129,118 @@ modulate_weight_kernel(T* __restrict__ out, const float* __restrict__ w, const f
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Batched forms: the style path is ~50 tiny independent GEMVs and 15 weight modulations per
+// frame; launching them one by one is pure launch latency (5-20 us each).  The tables travel
+// BY VALUE in the kernel argument block (no device-side table to keep alive, graph-capture
+// safe); a workgroup finds its item with a scalar scan of the wave/row prefix.
+// ---------------------------------------------------------------------------------
+constexpr int LIN_BATCH = 24, MOD_BATCH = 16;
+
+struct LinearTable {
+    vt_linear_item it[LIN_BATCH];
+    int32_t first_wave[LIN_BATCH + 1];
+    int32_t n;
+};
+
+__global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = t.first_wave[t.n];
+    const int wv = wave < total ? wave : total - 1;
+    int k = 0;
+    while (k + 1 < t.n && wv >= t.first_wave[k + 1]) ++k;
+    const vt_linear_item& L = t.it[k];
+    const int wi = wv - t.first_wave[k];
+    const int r = wi / L.out_dim, o = wi - r * L.out_dim;
+    const float* xr = L.x + (int64_t)r * L.ld_x;
+    const float* wr = L.W + (int64_t)o * L.in_dim;
+    float acc = 0.0f;
+    for (int i = lane; i < L.in_dim; i += 64) acc += xr[i] * wr[i];
+    acc = wave_sum(acc);
+    if (lane == 0 && wave < total) {
+        float v = acc * L.w_scale;
+        if (L.b) v += L.b[o] * L.b_scale;
+        if (L.act == VT_ACT_LRELU) v = ((v > 0.0f) ? v : v * L.slope) * L.gain;
+        L.y[(int64_t)r * L.ld_y + o] = v;
+    }
+}
+
+struct ModTable {
+    vt_modulate_item it[MOD_BATCH];
+    int32_t first_row[MOD_BATCH + 1];  // prefix of cout
+    int32_t n;
+};
+
+// One WORKGROUP (4 wavefronts) per output channel: the sum of squares over cin*k*k is reduced
+// by the four waves through LDS in a fixed order, then all 256 lanes write the packed row(s).
+template <typename T>
+__global__ void __launch_bounds__(256) modulate_batch_kernel(const ModTable t) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.first_row[k + 1]) ++k;
+    const vt_modulate_item& M = t.it[k];
+    const int co = blockIdx.x - t.first_row[k];
+    const int cout = M.cout, cin = M.cin, taps = M.k * M.k;
+    const int n = cin * taps;
+    const float* w = (const float*)M.weight;
+    const float* s = M.s;
+    const float* wc = w + (int64_t)co * n;  // [ci][a][b]
+    const float scale = M.scale;
+    float demod = 1.0f;
+    if (M.demodulate) {
+        float ss = 0.0f;
+        for (int i = tid; i < n; i += 256) {
+            const float v = scale * wc[i] * s[i / taps];
+            ss += v * v;
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wv] = ss;
+        __syncthreads();
+        demod = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) + 1e-8f);
+    }
+    T* out = (T*)M.out;
+    if (M.fir == nullptr) {
+        T* oc = out + (int64_t)co * n;  // [tap][ci]
+        for (int i = tid; i < n; i += 256) {
+            const int tap = i / cin, ci = i - tap * cin;
+            oc[i] = from_f32<T>(scale * wc[ci * taps + tap] * s[ci] * demod);
+        }
+    } else {
+        float K[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) K[i] = M.fir[i];
+        for (int ci = tid; ci < cin; ci += 256) {
+            float wm[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) wm[q] = scale * wc[ci * 9 + q] * s[ci] * demod;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int py = p >> 1, px = p & 1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const int u = 4 - 2 * ky - a + py;
+                            if (u < 0 || u > 3) continue;
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) {
+                                const int v = 4 - 2 * kx - b + px;
+                                if (v < 0 || v > 3) continue;
+                                acc += wm[a * 3 + b] * K[u * 4 + v];
+                            }
+                        }
+                        out[((int64_t)(p * cout + co) * 9 + (ky * 3 + kx)) * cin + ci] = from_f32<T>(acc);
+                    }
+            }
+        }
+    }
+}
+
 // out[co][tap][cd] = scale * w[co][map[cd]][tap]   (or 0 when map[cd] < 0)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -220,4 +332,63 @@ extern "C" int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_
         return VT_ERR_UNSUPPORTED;
     }
     return vt_check_launch("vt_pack_conv_weight");
+}
+
+extern "C" int vt_linear_batch(const vt_linear_item* items, int n_items, vt_stream stream) {
+    VT_REQUIRE(items && n_items >= 0, "vt_linear_batch: bad arguments");
+    for (int base = 0; base < n_items; base += LIN_BATCH) {
+        LinearTable t;
+        memset(&t, 0, sizeof(t));
+        t.n = (n_items - base < LIN_BATCH) ? n_items - base : LIN_BATCH;
+        int64_t waves = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const vt_linear_item& L = items[base + i];
+            VT_REQUIRE(L.y && L.x && L.W && L.rows > 0 && L.in_dim > 0 && L.out_dim > 0,
+                       "vt_linear_batch: item %d: bad tensor/sizes", base + i);
+            VT_REQUIRE(L.act == VT_ACT_NONE || L.act == VT_ACT_LRELU, "vt_linear_batch: unsupported act %d", L.act);
+            t.it[i] = L;
+            t.first_wave[i] = (int32_t)waves;
+            waves += (int64_t)L.rows * L.out_dim;
+        }
+        VT_REQUIRE(waves < ((int64_t)1 << 30), "vt_linear_batch: too many outputs");
+        t.first_wave[t.n] = (int32_t)waves;
+        if (waves == 0) continue;
+        VT_LAUNCH(linear_batch_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), stream, t);
+        const int rc = vt_check_launch("vt_linear_batch");
+        if (rc) return rc;
+    }
+    return VT_OK;
+}
+
+extern "C" int vt_modulate_weight_batch(const vt_modulate_item* items, int n_items, int out_dtype,
+                                        vt_stream stream) {
+    VT_REQUIRE(items && n_items >= 0, "vt_modulate_weight_batch: bad arguments");
+    VT_REQUIRE(out_dtype == VT_F32 || out_dtype == VT_BF16, "vt_modulate_weight_batch: unsupported dtype %d", out_dtype);
+    for (int base = 0; base < n_items; base += MOD_BATCH) {
+        ModTable t;
+        memset(&t, 0, sizeof(t));
+        t.n = (n_items - base < MOD_BATCH) ? n_items - base : MOD_BATCH;
+        int64_t rows = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const vt_modulate_item& M = items[base + i];
+            VT_REQUIRE(M.out && M.weight && M.s && M.cout > 0 && M.cin > 0 && (M.k == 1 || M.k == 3),
+                       "vt_modulate_weight_batch: item %d: bad tensor/shape", base + i);
+            VT_REQUIRE(!M.fir || M.k == 3, "vt_modulate_weight_batch: polyphase fold needs a 3x3 kernel");
+            t.it[i] = M;
+            t.first_row[i] = (int32_t)rows;
+            rows += M.cout;
+        }
+        t.first_row[t.n] = (int32_t)rows;
+        if (rows == 0) continue;
+        if (out_dtype == VT_F32) {
+            auto kf = modulate_batch_kernel<float>;
+            VT_LAUNCH(kf, dim3((unsigned)rows), dim3(256), stream, t);
+        } else {
+            auto kf = modulate_batch_kernel<bf16_t>;
+            VT_LAUNCH(kf, dim3((unsigned)rows), dim3(256), stream, t);
+        }
+        const int rc = vt_check_launch("vt_modulate_weight_batch");
+        if (rc) return rc;
+    }
+    return VT_OK;
 }

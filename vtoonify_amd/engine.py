@@ -174,7 +174,10 @@ class VToonifyEngine:
 
     # ------------------------------------------------------------------ style path
     def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
-        """ns = number of distinct style rows prepared (1 when the batch shares a style)."""
+        """ns = number of distinct style rows prepared (1 when the batch shares a style).
+
+        The ~50 GEMVs of the style path are grouped by dependency level into a handful of
+        vt_linear_batch launches, the 15 weight modulations into one vt_modulate_weight_batch."""
         sd, g, ops, lib = self.sd, self.g, plan.style_ops, self.lib
         f32 = torch.float32
         style_in = self._buf(plan, "style_in", (ns, N_LATENT, 512), f32)   # W+ rows
@@ -182,6 +185,18 @@ class VToonifyEngine:
         ds = self._buf(plan, "d_s", (1,), f32)
         ds1 = self._buf(plan, "d_s_rows", (ns, 1), f32)
         rows = ns * N_LATENT
+        levels: List[list] = [[] for _ in range(5)]
+
+        def lin(level, y, ld_y, x, ld_x, W, b, nrows, w_scale=1.0, b_scale=1.0, act=ACT_NONE, slope=0.2,
+                gain=1.0):
+            it = _lib.LinearItem()
+            it.y, it.x, it.W = K._ptr(y), K._ptr(x), W.data_ptr()
+            it.b = b.data_ptr() if b is not None else None
+            it.ld_y, it.ld_x, it.rows = ld_y, ld_x, nrows
+            it.out_dim, it.in_dim = W.shape
+            it.act, it.w_scale, it.b_scale, it.slope, it.gain = act, w_scale, b_scale, slope, gain
+            levels[level].append(it)
+
         if self.dual:
             # resstyles = generator.style(style)  (PixelNorm + 2 EqualLinear lr_mul=.01 fused lrelu;
             # model/dualstylegan.py:51-55, model/vtoonify.py:212-220)
@@ -191,22 +206,22 @@ class VToonifyEngine:
             ops.append((lib.vt_pixel_norm, (C.c_void_p(pn.data_ptr()), C.c_void_p(style_in.data_ptr()), rows, 512),
                         "pixel_norm"))
             sc = (1.0 / math.sqrt(512)) * 0.01
-            self._op_linear(ops, t1, 512, pn, 512, sd["generator.style.1.weight"], sd["generator.style.1.bias"],
-                            rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
-            self._op_linear(ops, res, 512, t1, 512, sd["generator.style.2.weight"], sd["generator.style.2.bias"],
-                            rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
-            # adastyles[:, i] = generator.res[i](adastyles[:, i]), i = 7..17 (vtoonify.py:221-224)
-            ops.append((self._copy_op, (ada, style_in), "copy"))
+            lin(0, t1, 512, pn, 512, sd["generator.style.1.weight"], sd["generator.style.1.bias"],
+                rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
+            lin(1, res, 512, t1, 512, sd["generator.style.2.weight"], sd["generator.style.2.bias"],
+                rows, sc, 0.01, ACT_LRELU, 0.2, SQRT2)
+            # adastyles[:, i] = generator.res[i](adastyles[:, i]), i = 7..17 (vtoonify.py:221-224);
+            # rows 0..6 are never read downstream (latent rows 7..17 feed the 15 synthesis convs)
             for i in range(7, N_LATENT):
-                self._op_linear(ops, ada.data_ptr() + i * 512 * 4, N_LATENT * 512,
-                                style_in.data_ptr() + i * 512 * 4, N_LATENT * 512,
-                                sd[f"generator.res.{i}.weight"], sd[f"generator.res.{i}.bias"], ns,
-                                1.0 / math.sqrt(512), 1.0)
+                lin(0, ada.data_ptr() + i * 512 * 4, N_LATENT * 512, style_in.data_ptr() + i * 512 * 4,
+                    N_LATENT * 512, sd[f"generator.res.{i}.weight"], sd[f"generator.res.{i}.bias"], ns,
+                    1.0 / math.sqrt(512), 1.0)
         else:
             ops.append((self._copy_op, (ada, style_in), "copy"))
 
         # modulation vectors + modulated weights of the 15 synthesis convs (model.py:259-267)
         plan.modw = {}
+        mods = []
         for lvl in range(5):
             for name, lat, demod, up in ((f"convs.{6 + 2 * lvl}", 7 + 2 * lvl, True, True),
                                          (f"convs.{7 + 2 * lvl}", 8 + 2 * lvl, True, False),
@@ -214,19 +229,21 @@ class VToonifyEngine:
                 w = self.modw[name]
                 cout, cin, k, _ = w.shape
                 s = self._buf(plan, f"s.{name}", (ns, cin), f32)
-                self._op_linear(ops, s, cin, ada.data_ptr() + lat * 512 * 4, N_LATENT * 512,
-                                sd[f"{g}{name}.conv.modulation.weight"], sd[f"{g}{name}.conv.modulation.bias"],
-                                ns, 1.0 / math.sqrt(512), 1.0)
+                lin(1, s, cin, ada.data_ptr() + lat * 512 * 4, N_LATENT * 512,
+                    sd[f"{g}{name}.conv.modulation.weight"], sd[f"{g}{name}.conv.modulation.bias"],
+                    ns, 1.0 / math.sqrt(512), 1.0)
                 phases = 4 if up else 1
                 taps = 9 if up else k * k
                 wm = self._buf(plan, f"wm.{name}", (ns, phases * cout, taps, cin))
                 plan.modw[name] = wm
                 for b in range(ns):
-                    ops.append((lib.vt_modulate_weight,
-                                (C.c_void_p(wm.data_ptr() + b * phases * cout * taps * cin * self.esz),
-                                 C.c_void_p(w.data_ptr()), C.c_void_p(s.data_ptr() + b * cin * 4), cout, cin, k,
-                                 1.0 / math.sqrt(cin * k * k), int(demod),
-                                 C.c_void_p(self.fir_up.data_ptr() if up else 0), self.dt), "modulate"))
+                    it = _lib.ModulateItem()
+                    it.out = wm.data_ptr() + b * phases * cout * taps * cin * self.esz
+                    it.weight, it.s = w.data_ptr(), s.data_ptr() + b * cin * 4
+                    it.fir = self.fir_up.data_ptr() if up else None
+                    it.cout, it.cin, it.k, it.demodulate = cout, cin, k, int(demod)
+                    it.scale = 1.0 / math.sqrt(cin * k * k)
+                    mods.append(it)
         if self.dual:
             if has_res:
                 # AdaIN gamma/beta of the 6 ModRes blocks (dualstylegan.py:16-18), rows resstyles[:, ii+1]
@@ -234,21 +251,37 @@ class VToonifyEngine:
                     for nm in ("norm", "norm2"):
                         Wl = sd[f"res.{ii}.{nm}.style.weight"]
                         gb = self._buf(plan, f"gb.res.{ii}.{nm}", (ns, Wl.shape[0]), f32)
-                        self._op_linear(ops, gb, Wl.shape[0], plan.bufs["resstyles"].data_ptr() + ii * 512 * 4,
-                                        N_LATENT * 512, Wl, sd[f"res.{ii}.{nm}.style.bias"], ns)
+                        lin(2, gb, Wl.shape[0], plan.bufs["resstyles"].data_ptr() + ii * 512 * 4,
+                            N_LATENT * 512, Wl, sd[f"res.{ii}.{nm}.style.bias"], ns)
             # Fusion: label = MLP(d_s) (vtoonify.py:114-124), then AdaIN linear(label)
             ops.append((self._fill_rows_op, (ds1, ds), "fill"))
             for fi in range(self.n_fuse):
                 p = f"fusion_out.{fi}."
                 l0 = self._buf(plan, f"lab0.{fi}", (ns, 64), f32)
                 l1 = self._buf(plan, f"lab1.{fi}", (ns, 128), f32)
-                self._op_linear(ops, l0, 64, ds1, 1, sd[p + "linear.0.weight"], sd[p + "linear.0.bias"], ns,
-                                1.0, 1.0, ACT_LRELU, 0.2, 1.0)
-                self._op_linear(ops, l1, 128, l0, 64, sd[p + "linear.2.weight"], sd[p + "linear.2.bias"], ns,
-                                1.0, 1.0, ACT_LRELU, 0.2, 1.0)
+                lin(0, l0, 64, ds1, 1, sd[p + "linear.0.weight"], sd[p + "linear.0.bias"], ns,
+                    1.0, 1.0, ACT_LRELU, 0.2, 1.0)
+                lin(1, l1, 128, l0, 64, sd[p + "linear.2.weight"], sd[p + "linear.2.bias"], ns,
+                    1.0, 1.0, ACT_LRELU, 0.2, 1.0)
                 Wl = sd[p + "norm.style.weight"]
                 gb = self._buf(plan, f"gb.fus.{fi}", (ns, Wl.shape[0]), f32)
-                self._op_linear(ops, gb, Wl.shape[0], l1, 128, Wl, sd[p + "norm.style.bias"], ns)
+                lin(2, gb, Wl.shape[0], l1, 128, Wl, sd[p + "norm.style.bias"], ns)
+        else:
+            # toonify: the modulation linears read `ada` straight after the copy
+            pass
+        # level 1 of the toonify backbone has no level-0 producers except the copy: still ordered
+        for lv in levels:
+            if not lv:
+                continue
+            arr = (_lib.LinearItem * len(lv))(*lv)
+            plan.keep.append(arr)
+            ops.append((lib.vt_linear_batch, (arr, len(lv)), {"name": "linear", "kernel": "linear_batch",
+                                                              "flops": 0, "bytes": 0}))
+        marr = (_lib.ModulateItem * len(mods))(*mods)
+        plan.keep.append(marr)
+        ops.append((lib.vt_modulate_weight_batch, (marr, len(mods), self.dt),
+                    {"name": "modulate", "kernel": "modulate_batch", "flops": 0,
+                     "bytes": sum(m.cout * m.cin * m.k * m.k * (4 + self.esz * (4 if m.fir else 1)) for m in mods)}))
 
     # tiny torch-side helpers used as plan ops (device-to-device copies; plumbing)
     @staticmethod
@@ -300,6 +333,7 @@ class VToonifyEngine:
             sc1 = self._buf(plan, "in_scale", (B, cf), f32)
             sh1 = self._buf(plan, "in_shift", (B, cf), f32)
             ws = self._buf(plan, "in_ws", (max(K.instnorm_ws_bytes(B, hw, cf), 16),), torch.uint8)
+            nrm_res = self._buf(plan, "nrm_res", (B, h, w, cf))
         feat = cur
         pp = 0
         rk = f"encoder.{self.n_down}"
@@ -325,18 +359,27 @@ class VToonifyEngine:
                                  0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
                                 {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
                                  "bytes": B * hw * cf * self.esz}))
+                    # AdaIN applied as its own streaming pass (1 MB at 32x32x512) so that the conv
+                    # runs the direct-to-LDS loader; the fused in-loader affine (in_scale/in_shift
+                    # of vt_conv2d) costs more in the MFMA loop than this pass does
+                    ops.append((lib.vt_affine_apply,
+                                (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf,
+                                 C.c_void_p(0), 0, C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()),
+                                 B, hw, cf, dt),
+                                {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                 "bytes": 2 * B * hw * cf * self.esz}))
                     cn = "conv" if nm == "norm" else "conv2"
                     if dst is not None:
-                        self._op_conv(ops, plan, src0=src, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                        self._op_conv(ops, plan, src0=nrm_res, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                                       weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
-                                      in_scale=sc1, in_shift=sh1, bias=sd[f"res.{r}.{cn}.1.bias"],
+                                      bias=sd[f"res.{r}.{cn}.1.bias"],
                                       act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf)
                     else:
                         nxt = ping[pp]; pp ^= 1
                         # out * d_s + skip  (d_s read from device memory: graph-replay safe)
-                        self._op_conv(ops, plan, src0=src, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                        self._op_conv(ops, plan, src0=nrm_res, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                                       weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
-                                      in_scale=sc1, in_shift=sh1, bias=sd[f"res.{r}.{cn}.1.bias"],
+                                      bias=sd[f"res.{r}.{cn}.1.bias"],
                                       act=ACT_LRELU, gain=SQRT2, alpha_dev=ds, beta=1.0, resid=feat, ld_res=cf,
                                       out=nxt, ld_out=cf)
                         feat = nxt
