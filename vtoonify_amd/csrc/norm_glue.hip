@@ -24,19 +24,23 @@ struct StatRec {
 // batch), so a frame's statistics -- hence its output bits -- are the same whether it is
 // processed alone or inside a batch.
 __host__ __device__ inline int stat_chunk_pixels(int hw) {
-    // ~256 chunks per image, 64..4096 pixels each
+    // ~256 chunks per image, 16..4096 pixels each
     int px = (hw + 255) / 256;
-    if (px < 64) px = 64;
+    if (px < 16) px = 16;
     if (px > 4096) px = 4096;
     return px;
 }
 
+// One workgroup reduces a chunk of pixels for ALL channels in a single pass: x (and `other`) are
+// read once, the statistics of x and of |x - other| are accumulated together, 4 pixels per
+// thread are in flight (independent accumulators, merged in a fixed order).
 template <typename T>
 __global__ void __launch_bounds__(256)
 instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int ld_x,
                         const T* __restrict__ other, int ld_o, int hw, int c, int chunk_px,
                         int chunks) {
     constexpr int VEC = 16 / sizeof(T);
+    constexpr int UNR = 4;
     __shared__ float red[256 * VEC * 2];
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x % chunks, img = blockIdx.x / chunks;
@@ -55,45 +59,63 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
     for (int cbase = 0; cbase < cvn; cbase += cpar) {
         const int cv = cbase + cv0;
         const bool on = active && cv < cvn;
-        for (int half = 0; half < halves; ++half) {
-            float x0[VEC], s1[VEC], s2[VEC];
+        float x0[2][VEC], s1[2][UNR][VEC], s2[2][UNR][VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) x0[i] = s1[i] = s2[i] = 0.0f;
-            if (on) {
-                {
-                    float f[VEC];
-                    unpack16<T>(ld128(xb + (int64_t)p_lo * ld_x + cv * VEC), f);
-                    if (half == 1) {
-                        float g[VEC];
-                        unpack16<T>(ld128(ob + (int64_t)p_lo * ld_o + cv * VEC), g);
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) f[i] = fabsf(f[i] - g[i]);
-                    }
+            for (int i = 0; i < VEC; ++i) {
+                x0[h][i] = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) x0[i] = f[i];
+                for (int u = 0; u < UNR; ++u) s1[h][u][i] = s2[h][u][i] = 0.0f;
+            }
+        if (on) {
+            {   // shift = the chunk's first pixel (kills the E[x^2]-E[x]^2 cancellation)
+                float f[VEC];
+                unpack16<T>(ld128(xb + (int64_t)p_lo * ld_x + cv * VEC), f);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) x0[0][i] = f[i];
+                if (ob) {
+                    float g[VEC];
+                    unpack16<T>(ld128(ob + (int64_t)p_lo * ld_o + cv * VEC), g);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) x0[1][i] = fabsf(f[i] - g[i]);
                 }
-                for (int px = p_lo + prow; px < p_hi; px += rows) {
-                    float f[VEC];
-                    unpack16<T>(ld128(xb + (int64_t)px * ld_x + cv * VEC), f);
-                    if (half == 1) {
-                        float g[VEC];
-                        unpack16<T>(ld128(ob + (int64_t)px * ld_o + cv * VEC), g);
+            }
+            for (int px = p_lo + prow; px < p_hi; px += rows * UNR) {
+                u128 vx[UNR], vo[UNR];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) f[i] = fabsf(f[i] - g[i]);
-                    }
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = px + u * rows;
+                    const bool in = q < p_hi;
+                    vx[u] = in ? ld128(xb + (int64_t)q * ld_x + cv * VEC) : zero128();
+                    vo[u] = (in && ob) ? ld128(ob + (int64_t)q * ld_o + cv * VEC) : zero128();
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (px + u * rows >= p_hi) continue;
+                    float f[VEC], g[VEC];
+                    unpack16<T>(vx[u], f);
+                    unpack16<T>(vo[u], g);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
-                        const float d = f[i] - x0[i];
-                        s1[i] += d;
-                        s2[i] += d * d;
+                        const float d = f[i] - x0[0][i];
+                        s1[0][u][i] += d;
+                        s2[0][u][i] += d * d;
+                        if (ob) {
+                            const float e = fabsf(f[i] - g[i]) - x0[1][i];
+                            s1[1][u][i] += e;
+                            s2[1][u][i] += e * e;
+                        }
                     }
                 }
             }
+        }
+        for (int half = 0; half < halves; ++half) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                red[(tid * VEC + i) * 2 + 0] = s1[i];
-                red[(tid * VEC + i) * 2 + 1] = s2[i];
+                red[(tid * VEC + i) * 2 + 0] = (s1[half][0][i] + s1[half][1][i]) + (s1[half][2][i] + s1[half][3][i]);
+                red[(tid * VEC + i) * 2 + 1] = (s2[half][0][i] + s2[half][1][i]) + (s2[half][2][i] + s2[half][3][i]);
             }
             __syncthreads();
             // thread (prow == 0) of each channel-vector folds the pixel rows in order
@@ -106,7 +128,7 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
                         a2 += red[(t * VEC + i) * 2 + 1];
                     }
                     StatRec rec;
-                    rec.x0 = x0[i];
+                    rec.x0 = x0[half][i];
                     rec.s1 = a1;
                     rec.s2 = a2;
                     part[((int64_t)img * chunks + chunk) * ctot + half * c + cv * VEC + i] = rec;

@@ -146,10 +146,20 @@ struct LinearTable {
 __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int total = t.first_wave[t.n];
+    // the prefix table goes through LDS once per workgroup: a dependent chain of up to 24 scalar
+    // loads from the argument block per wave cost ~10 us (measured), a 5-step LDS search nothing
+    __shared__ int pre[LIN_BATCH + 1];
+    if (threadIdx.x <= (unsigned)t.n) pre[threadIdx.x] = t.first_wave[threadIdx.x];
+    __syncthreads();
+    const int total = pre[t.n];
     const int wv = wave < total ? wave : total - 1;
-    int k = 0;
-    while (k + 1 < t.n && wv >= t.first_wave[k + 1]) ++k;
+    int lo = 0, hi = t.n;  // invariant: pre[lo] <= wv < pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wv >= pre[mid]) lo = mid;
+        else hi = mid;
+    }
+    const int k = lo;
     const vt_linear_item& L = t.it[k];
     const int wi = wv - t.first_wave[k];
     const int r = wi / L.out_dim, o = wi - r * L.out_dim;
@@ -178,8 +188,13 @@ template <typename T>
 __global__ void __launch_bounds__(256) modulate_batch_kernel(const ModTable t) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int k = 0;
-    while (k + 1 < t.n && (int)blockIdx.x >= t.first_row[k + 1]) ++k;
+    int lo = 0, hi = t.n;  // binary search of the row prefix (scalar loads, <= 4 steps)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x >= t.first_row[mid]) lo = mid;
+        else hi = mid;
+    }
+    const int k = lo;
     const vt_modulate_item& M = t.it[k];
     const int co = blockIdx.x - t.first_row[k];
     const int cout = M.cout, cin = M.cin, taps = M.k * M.k;
