@@ -55,7 +55,7 @@ struct ConvArgs {
     int act;
     float slope, gain_alpha, beta;
     int ld_res, ld_out, out_layout, out_f32, vec_store;
-    int M, tiles_n;
+    int M, tiles_n, tiles_m;
     // split-K: each tile's K range is cut into `splitk` slices of `kps` K-steps; slice s
     // writes raw fp32 accumulators to partial[s][m][ldp] and conv_splitk_reduce finishes.
     int splitk, kps, ldp;
@@ -165,6 +165,24 @@ __device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float b
     return v * ga;
 }
 
+// XCD-aware block -> (tile_m, tile_n, K-slice) mapping.  Workgroup b is dispatched to XCD b % 8
+// (observed, MI355X_MICROARCH.md); each XCD has its own 4 MiB L2.  Blocks are renumbered so that
+// XCD x owns one contiguous range of the logical order [tile_n][tile_m][slice]: all tiles that
+// read the same weight rows (tile_n) -- and neighbouring pixel tiles, which share halo rows --
+// run on the same XCD, so a conv's weight matrix is fetched from HBM/MALL once, not once per
+// XCD.  Pure speed: any placement gives the same results.  Bijective for every grid size.
+__device__ __forceinline__ void decode_block(const ConvArgs& p, int& tile_m, int& tile_n, int& split) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_n = p.tiles_m * p.splitk;
+    tile_n = L / per_n;
+    const int rem = L - tile_n * per_n;
+    tile_m = rem / p.splitk;
+    split = rem - tile_m * p.splitk;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               unsigned char* smem, int m0, int n0, int split) {
@@ -266,8 +284,8 @@ conv_igemm_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x / p.splitk, split = blockIdx.x - tile * p.splitk;
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader state -----------------------------------------------------------
@@ -460,8 +478,8 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     const int lane = tid & 63;
     const int wave = vt_uniform(tid >> 6) & 3;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x / p.splitk, split = blockIdx.x - tile * p.splitk;
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HoWo = p.Ho * p.Wo;
 
@@ -675,6 +693,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
     args.tiles_n = vt_cdiv(a.coutT, BN);
+    args.tiles_m = vt_cdiv(a.M, BM);
     const int nk = vt_cdiv(a.K, BK);
     if (args.splitk > 1) {
         args.kps = vt_cdiv(nk, args.splitk);
@@ -741,11 +760,11 @@ static void choose_tile(const ConvArgs& a, int hint, int ws_floats_avail, int bk
     }
     const int nk = vt_cdiv(a.K, bk);
     if (splitk == 0) {
-        // too few tiles to fill 256 CUs: cut K so that ~768 workgroups exist, >= 2 K-steps each
+        // too few tiles to fill 256 CUs: cut K so that ~512 workgroups exist, >= 2 K-steps each
         splitk = 1;
         const int64_t t = tiles(bm, bn);
         if (t < 384 && nk >= 4) {
-            int64_t s = (768 + t - 1) / t;
+            int64_t s = (512 + t - 1) / t;
             if (s > nk / 2) s = nk / 2;
             if (s > 32) s = 32;
             splitk = (int)s;

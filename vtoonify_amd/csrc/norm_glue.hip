@@ -32,15 +32,16 @@ __host__ __device__ inline int stat_chunk_pixels(int hw) {
 }
 
 // One workgroup reduces a chunk of pixels for ALL channels in a single pass: x (and `other`) are
-// read once, the statistics of x and of |x - other| are accumulated together, 4 pixels per
-// thread are in flight (independent accumulators, merged in a fixed order).
-template <typename T>
+// read once, the statistics of x and of |x - other| are accumulated together, and 4 pixels per
+// thread are in flight (independent 16-byte loads, accumulated in pixel order).
+template <typename T, bool HAS_OTHER>
 __global__ void __launch_bounds__(256)
 instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int ld_x,
                         const T* __restrict__ other, int ld_o, int hw, int c, int chunk_px,
                         int chunks) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int UNR = 4;
+    constexpr int HALVES = HAS_OTHER ? 2 : 1;
     __shared__ float red[256 * VEC * 2];
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x % chunks, img = blockIdx.x / chunks;
@@ -51,34 +52,27 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
     const int rows = 256 / cpar;             // pixel rows handled in parallel
     const int cv0 = tid % cpar, prow = tid / cpar;
     const bool active = prow < rows;
-    const int halves = other ? 2 : 1;
-    const int ctot = c * halves;
+    const int ctot = c * HALVES;
     const T* xb = x + (int64_t)img * hw * ld_x;
-    const T* ob = other ? other + (int64_t)img * hw * ld_o : nullptr;
+    const T* ob = HAS_OTHER ? other + (int64_t)img * hw * ld_o : nullptr;
 
     for (int cbase = 0; cbase < cvn; cbase += cpar) {
         const int cv = cbase + cv0;
         const bool on = active && cv < cvn;
-        float x0[2][VEC], s1[2][UNR][VEC], s2[2][UNR][VEC];
+        float x0a[VEC], s1a[VEC], s2a[VEC], x0b[VEC], s1b[VEC], s2b[VEC];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                x0[h][i] = 0.0f;
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) s1[h][u][i] = s2[h][u][i] = 0.0f;
-            }
+        for (int i = 0; i < VEC; ++i) x0a[i] = s1a[i] = s2a[i] = x0b[i] = s1b[i] = s2b[i] = 0.0f;
         if (on) {
             {   // shift = the chunk's first pixel (kills the E[x^2]-E[x]^2 cancellation)
                 float f[VEC];
                 unpack16<T>(ld128(xb + (int64_t)p_lo * ld_x + cv * VEC), f);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) x0[0][i] = f[i];
-                if (ob) {
+                for (int i = 0; i < VEC; ++i) x0a[i] = f[i];
+                if (HAS_OTHER) {
                     float g[VEC];
                     unpack16<T>(ld128(ob + (int64_t)p_lo * ld_o + cv * VEC), g);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) x0[1][i] = fabsf(f[i] - g[i]);
+                    for (int i = 0; i < VEC; ++i) x0b[i] = fabsf(f[i] - g[i]);
                 }
             }
             for (int px = p_lo + prow; px < p_hi; px += rows * UNR) {
@@ -86,40 +80,42 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int q = px + u * rows;
-                    const bool in = q < p_hi;
-                    vx[u] = in ? ld128(xb + (int64_t)q * ld_x + cv * VEC) : zero128();
-                    vo[u] = (in && ob) ? ld128(ob + (int64_t)q * ld_o + cv * VEC) : zero128();
+                    const int qq = q < p_hi ? q : p_lo;  // clamp: keep every load unconditional
+                    vx[u] = ld128(xb + (int64_t)qq * ld_x + cv * VEC);
+                    if (HAS_OTHER) vo[u] = ld128(ob + (int64_t)qq * ld_o + cv * VEC);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    if (px + u * rows >= p_hi) continue;
+                    const float live = (px + u * rows < p_hi) ? 1.0f : 0.0f;
                     float f[VEC], g[VEC];
                     unpack16<T>(vx[u], f);
-                    unpack16<T>(vo[u], g);
+                    if (HAS_OTHER) unpack16<T>(vo[u], g);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
-                        const float d = f[i] - x0[0][i];
-                        s1[0][u][i] += d;
-                        s2[0][u][i] += d * d;
-                        if (ob) {
-                            const float e = fabsf(f[i] - g[i]) - x0[1][i];
-                            s1[1][u][i] += e;
-                            s2[1][u][i] += e * e;
+                        const float d = (f[i] - x0a[i]) * live;
+                        s1a[i] += d;
+                        s2a[i] += d * d;
+                        if (HAS_OTHER) {
+                            const float e = (fabsf(f[i] - g[i]) - x0b[i]) * live;
+                            s1b[i] += e;
+                            s2b[i] += e * e;
                         }
                     }
                 }
             }
         }
-        for (int half = 0; half < halves; ++half) {
+#pragma unroll
+        for (int half = 0; half < HALVES; ++half) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                red[(tid * VEC + i) * 2 + 0] = (s1[half][0][i] + s1[half][1][i]) + (s1[half][2][i] + s1[half][3][i]);
-                red[(tid * VEC + i) * 2 + 1] = (s2[half][0][i] + s2[half][1][i]) + (s2[half][2][i] + s2[half][3][i]);
+                red[(tid * VEC + i) * 2 + 0] = half ? s1b[i] : s1a[i];
+                red[(tid * VEC + i) * 2 + 1] = half ? s2b[i] : s2a[i];
             }
             __syncthreads();
             // thread (prow == 0) of each channel-vector folds the pixel rows in order
             if (on && prow == 0) {
+#pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float a1 = 0.0f, a2 = 0.0f;
                     for (int r = 0; r < rows; ++r) {
@@ -128,7 +124,7 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
                         a2 += red[(t * VEC + i) * 2 + 1];
                     }
                     StatRec rec;
-                    rec.x0 = x0[half][i];
+                    rec.x0 = half ? x0b[i] : x0a[i];
                     rec.s1 = a1;
                     rec.s2 = a2;
                     part[((int64_t)img * chunks + chunk) * ctot + half * c + cv * VEC + i] = rec;
@@ -331,15 +327,18 @@ extern "C" int vt_instnorm_stats(float* scale, float* shift, const void* x, int 
     const int chunks = (hw + cpx - 1) / cpx;
     const int ctot = absdiff_other ? 2 * c : c;
     dim3 grid((unsigned)(n * chunks)), block(256);
-    if (dtype == VT_F32) {
-        auto k = instnorm_partial_kernel<float>;
-        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const float*)x, ld_x,
-                  (const float*)absdiff_other, ld_other, hw, c, cpx, chunks);
-    } else {
-        auto k = instnorm_partial_kernel<bf16_t>;
-        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const bf16_t*)x, ld_x,
-                  (const bf16_t*)absdiff_other, ld_other, hw, c, cpx, chunks);
+#define VT_IN_LAUNCH(TT, HO)                                                                        \
+    {                                                                                               \
+        auto k = instnorm_partial_kernel<TT, HO>;                                                   \
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const TT*)x, ld_x,                   \
+                  (const TT*)absdiff_other, ld_other, hw, c, cpx, chunks);                          \
     }
+    if (dtype == VT_F32) {
+        if (absdiff_other) VT_IN_LAUNCH(float, true) else VT_IN_LAUNCH(float, false)
+    } else {
+        if (absdiff_other) VT_IN_LAUNCH(bf16_t, true) else VT_IN_LAUNCH(bf16_t, false)
+    }
+#undef VT_IN_LAUNCH
     int rc = vt_check_launch("vt_instnorm_stats(partial)");
     if (rc) return rc;
     VT_LAUNCH(instnorm_finalize_kernel, dim3((unsigned)(n * (ctot / 16))), dim3(256), stream,
