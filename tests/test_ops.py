@@ -154,7 +154,7 @@ def test_mfma_lane_maps(dev):
 
 # ----------------------------------------------------------------------------- conv_igemm
 def _conv_case(dev, dtype, N, Cin, H, W, Cout, k, stride, pad, dil, act=0, resid=False, planar=False, hint=0,
-               seed=0):
+               seed=0, ws=False, expect_kind=None):
     g = np.random.default_rng(seed)
     x = g.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (g.standard_normal((Cout, Cin, k, k)) / math.sqrt(Cin * k * k)).astype(np.float32)
@@ -176,6 +176,14 @@ def _conv_case(dev, dtype, N, Cin, H, W, Cout, k, stride, pad, dil, act=0, resid
     common = dict(src0=xt, c0=cpad, ld0=cpad, n=N, h=H, w=W, out_h=Ho, out_w=Wo, weight=wp, cout=Cout, kh=k, kw=k,
                   stride=stride, pad=pad, dil=dil, bias=T(b, dev), act=act, gain=gain, dtype=K.dt_code(dtype),
                   tile_hint=hint, alpha=0.5 if resid else 1.0, beta=0.25 if resid else 0.0)
+    if ws:  # split-K workspace: lets the heuristics (or the hint) cut K across workgroups
+        common["splitk_ws"] = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+    if expect_kind is not None:
+        import ctypes
+        from vtoonify_amd import _lib
+        d = K.make_conv_desc(out=xt, ld_out=8, **common)
+        code = _lib.lib().vt_conv2d_tile(ctypes.byref(d))
+        assert code // 100000000 == expect_kind, f"kernel kind {code}"
     if planar:
         out = torch.zeros((N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
         r = None
@@ -217,6 +225,55 @@ def test_conv_every_tile(dev, hint):
     for dtype in (torch.float32, torch.bfloat16):
         t = F32_TOL if dtype == torch.float32 else 8e-3
         assert _conv_case(dev, dtype, 1, 48, 10, 13, 136, 3, 1, 1, 1, act=K.ACT_LRELU, hint=hint, resid=True) < t
+
+
+P = 100000000  # tile-code digit of the patch-resident kernel
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
+    """cin % 64 == 0 (bf16) / % 32 (fp32) makes a conv eligible for the buffer_load->LDS loaders;
+    3x3 stride-1 pad==dil additionally for the patch-resident kernel.  Odd sizes exercise the
+    zero-fill padding (out-of-range buffer offsets), 2-D tile edges, batches and split-K."""
+    t = F32_TOL if dtype == torch.float32 else 8e-3
+    L = K.ACT_LRELU
+    # patch kernel, auto plan (small image => 128x64 tiles + split-K over channel chunks)
+    assert _conv_case(dev, dtype, 2, 128, 19, 37, 64, 3, 1, 1, 1, act=L, resid=True, ws=True, expect_kind=1) < t
+    assert _conv_case(dev, dtype, 1, 64, 9, 21, 72, 3, 1, 2, 2, act=L, ws=True, expect_kind=1) < t     # dil 2
+    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=1) < t          # dil 4
+    assert _conv_case(dev, dtype, 1, 192, 8, 8, 1, 3, 1, 1, 1, act=K.ACT_RELU_TANH, planar=True, ws=True,
+                      expect_kind=1) < t                                                               # mask conv
+    # every compiled patch tile, forced by hint (S=0: auto split; S=2 forced)
+    for hint in (P + 256128, P + 256064, P + 128064, P + 128016, P + 2000000 + 128064, P + 2000000 + 256128):
+        assert _conv_case(dev, dtype, 1, 128, 21, 35, 136, 3, 1, 1, 1, act=L, hint=hint, resid=True, ws=True,
+                          seed=hint % 97) < t, hint
+    # 1-D direct-to-LDS kernels (patch disabled with P=2), incl. stride 2 and a 1x1 conv, with split-K
+    for hint in (2 * P + 128128, 2 * P + 64064, 2 * P + 4000000 + 64064, 2 * P + 128064, 2 * P + 64128):
+        assert _conv_case(dev, dtype, 2, 64, 13, 10, 136, 3, 1, 1, 1, act=L, hint=hint, resid=True, ws=True,
+                          expect_kind=0) < t, hint
+    assert _conv_case(dev, dtype, 1, 128, 13, 18, 64, 3, 2, 1, 1, act=L, ws=True, expect_kind=0) < t   # stride 2
+    assert _conv_case(dev, dtype, 2, 64, 9, 7, 3, 1, 1, 0, 1, planar=True, resid=True, ws=True) < t    # 1x1
+
+
+def test_conv_batch_invariance(dev):
+    """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
+    batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""
+    g = np.random.default_rng(5)
+    x = g.standard_normal((3, 128, 12, 20)).astype(np.float32)
+    w = (g.standard_normal((64, 128, 3, 3)) / 30).astype(np.float32)
+    wp = K.pack_conv_weight(T(w, dev), out_dtype=torch.bfloat16)
+    ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+
+    def run(xb):
+        xt = K.nchw_to_nhwc(T(xb, dev), torch.bfloat16)
+        out = torch.zeros((xb.shape[0], 12, 20, 64), dtype=torch.bfloat16, device=dev)
+        K.conv2d(src0=xt, c0=128, ld0=128, n=xb.shape[0], h=12, w=20, out_h=12, out_w=20, weight=wp, cout=64,
+                 kh=3, kw=3, pad=1, out=out, ld_out=64, dtype=K.VT_BF16, splitk_ws=ws)
+        return out
+
+    yb = run(x)
+    for i in range(3):
+        assert torch.equal(yb[i:i + 1], run(x[i:i + 1])), i
 
 
 def test_conv_concat_prologue_transposed(dev):

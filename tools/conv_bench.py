@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--nosplit", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the register-staged loader")
+    ap.add_argument("--nopatch", action="store_true", help="disable the patch-resident kernel")
     args = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
@@ -87,7 +88,7 @@ def main():
             kw = dict(out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32)
         d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout,
                              kh=k, kw=k, stride=stride, pad=pad, dil=dil, phases=phases, bias=bias,
-                             act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint + (1000000000 if args.generic else 0), **kw)
+                             act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint + (1000000000 if args.generic else 0) + (200000000 if args.nopatch else 0), **kw)
         if not args.nosplit:
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         tile = lib.vt_conv2d_tile(C.byref(d))

@@ -183,11 +183,29 @@ __device__ __forceinline__ void decode_block(const ConvArgs& p, int& tile_m, int
     split = rem - tile_m * p.splitk;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// GEMM row of a tile -> global GEMM row m (or -1 when the row is padding)
+struct LinearRows {   // 1-D tiles: BM consecutive pixels of the flattened (n, oy, ox) index
+    int m0, M;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int m = m0 + row;
+        return m < M ? m : -1;
+    }
+};
+template <int TW>
+struct PatchRows {    // 2-D tiles of TW-pixel rows (patch-resident kernel)
+    int img, y0, x0, Ho, Wo;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int oy = y0 + row / TW, ox = x0 + row % TW;
+        return (oy < Ho && ox < Wo) ? (img * Ho + oy) * Wo + ox : -1;
+    }
+};
+
+template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
-                                              unsigned char* smem, int m0, int n0, int split) {
+                                              unsigned char* smem, const RowMap rowmap, int n0, int split) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int SROWS = WM * 16, SLD = BN + 4;
+    constexpr int NT = WM * WN * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -203,8 +221,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                 const int n = n0 + wn * (TN * 16) + b * 16 + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (TM * 16) + a * 16 + q * 4 + r;
-                    if (m < p.M && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
+                    const int m = rowmap(wm * (TM * 16) + a * 16 + q * 4 + r);
+                    if (m >= 0 && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
                 }
             }
         return;
@@ -229,11 +247,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         __syncthreads();
         if (p.out_layout == VT_OUT_NHWC) {
             constexpr int CV = BN / 8;
-            for (int idx = tid; idx < SROWS * CV; idx += 256) {
+            for (int idx = tid; idx < SROWS * CV; idx += NT) {
                 const int row_l = idx / CV, cv = idx - row_l * CV;
-                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int m = rowmap((row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15));
                 const int n = n0 + cv * 8;
-                if (m >= p.M || n >= p.coutT) continue;
+                if (m < 0 || n >= p.coutT) continue;
                 float f[8];
                 {
                     const u128 lo = ld128(stage + row_l * SLD + cv * 8);
@@ -247,11 +265,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
             float* o = (float*)p.out;
             const float* rs = (const float*)p.resid;
-            for (int idx = tid; idx < SROWS * BN; idx += 256) {
+            for (int idx = tid; idx < SROWS * BN; idx += NT) {
                 const int col = idx / SROWS, row_l = idx - col * SROWS;
-                const int m = m0 + (row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15);
+                const int m = rowmap((row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15));
                 const int n = n0 + col;
-                if (m >= p.M || n >= p.coutT) continue;
+                if (m < 0 || n >= p.coutT) continue;
                 const int img = m / HoWo;
                 const int rem = m - img * HoWo;
                 const int64_t off = ((int64_t)img * p.cout + n) * HoWo + rem;
@@ -423,7 +441,7 @@ conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, split);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -607,7 +625,177 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
         nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
     }
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, split);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split);
+}
+
+// ---------------------------------------------------------------------------------------
+// Patch-resident 3x3 kernel (stride 1, pad == dilation): the direct-to-LDS GEMM above re-fetches
+// every input pixel once per filter tap (9x) and every weight once per pixel tile, and runs out of
+// L2->LDS bandwidth (~10 TB/s measured) long before the MFMA pipe.  Here a workgroup owns a 2-D
+// tile of TH x 16 output pixels; per 64-channel chunk it fetches the input PATCH (tile + halo,
+// (TH+2d) x (16+2d) pixels) ONCE and runs all 9 taps out of it -- an A fragment for tap (ky,kx)
+// is just the 16 patch pixels shifted by (ky*d, kx*d), i.e. 16 consecutive LDS rows, so the XOR
+// swizzle stays conflict-free.  Only the weights stream per tap (3-stage ring).  L2->LDS bytes
+// per MAC drop ~3x (A: 9x fewer, B: halved again by the 256-pixel tile of the 8-wave variant).
+//   K order: [chunk][tap]  (same products as [tap][chunk], different fp32 summation order)
+//   split-K: slices are whole chunks.
+// ---------------------------------------------------------------------------------------
+template <typename T, int TH, int BN, int WM, int WN, int DIL>
+__global__ void __launch_bounds__(WM * WN * 64)
+conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
+    constexpr int TW = 16;
+    constexpr int NW = WM * WN;                 // wavefronts
+    constexpr int BM = TH * TW;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VEC = 16 / ESZ;
+    constexpr int BK = 8 * VEC;                 // channels per chunk (128 B)
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, PROWS = PH * PW;
+    constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch loads per wave per chunk
+    constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
+    constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
+    constexpr int NSTB = 3, JA = 3;
+    constexpr int SROWS = WM * 16, SLD = BN + 4;
+    static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiling");
+    static_assert(TM * WM == TH, "one 16-pixel tile row per MFMA row block");
+    static_assert(SROWS * SLD * 4 <= 2 * A_BYTES + NSTB * B_BYTES, "epilogue staging must fit");
+    static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LB + PA < 64, "vmcnt is 6 bits");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
+    auto sA = [&](int b) -> unsigned char* { return smem + b * A_BYTES; };
+    auto sB = [&](int b) -> unsigned char* { return smem + 2 * A_BYTES + b * B_BYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (NW - 1);
+    const int wm = wave / WN, wn = wave % WN;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int n0 = tile_n * BN;
+
+    // ---- loader state (fixed for the whole kernel: only the SGPR offset moves) -------------
+    const int lrow = lane >> 3;
+    const int jj = (lane & 7) ^ lrow;
+    uint32_t pa0[PA], pa1[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pr = (i * NW + wave) * 8 + lrow;
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 - DIL + py, ix = x0 - DIL + px;
+        const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
+        pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
+        pa1[i] = in ? pix * (uint32_t)(p.ld1 * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    uint32_t woff[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int n = n0 + row;
+        woff[i] = (row < BN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
+    const BufRsrc r1 = vt_make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? g.nrec1 : 0u);
+    const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
+
+    // K slices are whole chunks: p.kps chunks per slice
+    const int nchunks = p.cin / BK;
+    const int ch0 = split * p.kps;
+    const int ch1 = (ch0 + p.kps < nchunks) ? ch0 + p.kps : nchunks;
+    const int nsteps = (ch1 - ch0) * 9;
+
+    auto issue_a = [&](int chunk, int abuf) {
+        const int kc = chunk * BK;
+        const bool s1 = kc >= p.c0;
+        const uint32_t so = (uint32_t)((s1 ? kc - p.c0 : kc) * ESZ);
+        if (s1) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) vt_glds16(r1, sA(abuf) + (i * NW + wave) * 1024, pa1[i], so);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) vt_glds16(r0, sA(abuf) + (i * NW + wave) * 1024, pa0[i], so);
+        }
+    };
+    auto issue_b = [&](int step, int bbuf) {   // step = (chunk - ch0) * 9 + tap
+        const int cl = step / 9, tap = step - cl * 9;
+        const uint32_t so = (uint32_t)((tap * p.cin + (ch0 + cl) * BK) * ESZ);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) vt_glds16(rw, sB(bbuf) + (i * NW + wave) * 1024, woff[i], so);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
+    const int b_row0 = wn * (TN * 16) + l15;
+
+    // prologue: patch of the first chunk + two weight steps in flight; patch and step 0 landed
+    issue_a(ch0, 0);
+    issue_b(0, 0);
+    if (nsteps > 1) {
+        issue_b(1, 1);
+        vt_glds_wait_n<LB>();
+    } else {
+        vt_glds_wait_n<0>();
+    }
+    vt_lds_barrier();
+
+    int abuf = 0, bbuf = 0, nbbuf = 2, tap = 0, chunk = ch0;
+    int a_age = 99;  // steps since the next chunk's patch was issued (99 = none in flight)
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more_b = s + 2 < nsteps;
+        if (more_b) issue_b(s + 2, nbbuf);
+        if (tap == JA && chunk + 1 < ch1) {
+            issue_a(chunk + 1, abuf ^ 1);
+            a_age = 0;
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int slot = sub * 4 + q;
+            u128 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int pr = (wm * TM + a + ky * DIL) * PW + kx * DIL + l15;
+                fa[a] = ld128(sA(abuf) + pr * 128 + ((slot ^ (pr & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = ld128(sB(bbuf) + (b_row0 + b * 16) * 128 + ((slot ^ l7) << 4));
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+        }
+        // Before step s+1 is read: its weights (issued in step s-1) must have landed, and -- at a
+        // chunk boundary -- the next patch.  Loads younger than B(s+1): the patch issued in step
+        // s-1 or s, and B(s+2).
+        const bool b_out = more_b;
+        const bool a_out = a_age <= 1 && !(tap == 8);   // patch still allowed in flight
+        if (b_out && a_out) vt_glds_wait_n<LB + PA>();
+        else if (a_out) vt_glds_wait_n<PA>();
+        else if (b_out) vt_glds_wait_n<LB>();
+        else vt_glds_wait_n<0>();
+        vt_lds_barrier();
+        if (a_age < 99) ++a_age;
+        bbuf = (bbuf + 1 == NSTB) ? 0 : bbuf + 1;
+        nbbuf = (nbbuf + 1 == NSTB) ? 0 : nbbuf + 1;
+        if (++tap == 9) {
+            tap = 0;
+            ++chunk;
+            abuf ^= 1;
+            a_age = 99;
+        }
+    }
+    __syncthreads();
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split);
 }
 
 // Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
@@ -729,63 +917,176 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     return vt_check_launch("vt_conv2d(split-K reduce)");
 }
 
-// Tile selection shared by vt_conv2d and vt_conv2d_tile (bench / profiling use the latter to
-// name the kernel instance a descriptor runs on).
-// Every choice below is a function of the PER-IMAGE geometry (Ho*Wo, cout, K) only -- never of
-// the batch -- so each output element sees the same K-chunking whether its frame is processed
-// alone or in a batch (bit-identical results; tests/test_engine.py).
-static void choose_tile(const ConvArgs& a, int hint, int ws_floats_avail, int bk, int& bm, int& bn, int& splitk) {
+// ---------------------------------------------------------------------------------------
+// Kernel / tile / split-K selection, shared by vt_conv2d, vt_conv2d_tile and
+// vt_conv2d_ws_bytes.  Every choice is a function of the PER-IMAGE geometry (Ho*Wo, cout, K)
+// only -- never of the batch -- so each output element sees the same K-chunking whether its
+// frame is processed alone or in a batch (bit-identical results; tests/test_engine.py).
+//
+// tile code (tile_hint / vt_conv2d_tile):  G*1e9 + P*1e8 + S*1e6 + BM*1e3 + BN
+//   G 1 = force the register-staged loader;  P 1 = patch-resident kernel (BM = 16*TH),
+//   P 2 (hint only) = never use the patch kernel;  S = split-K slices (0 = auto in a hint)
+// ---------------------------------------------------------------------------------------
+struct TilePlan {
+    int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel
+    int bm, bn, splitk;
+};
+
+template <typename T>
+static bool patch_eligible(const ConvArgs& a, GldsArgs& g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BK = 8 * (16 / ESZ);
+    if (a.force_generic || a.transposed || a.in_scale) return false;
+    if (a.taps != 9 || a.kw != 3 || a.stride != 1 || a.pad != a.dil) return false;
+    if (a.dil != 1 && a.dil != 2 && a.dil != 4) return false;
+    if (a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.c0 % BK != 0 || a.c1 % BK != 0) return false;
+    const int64_t lim = ((int64_t)1 << 31) - 4096;
+    const int64_t px = (int64_t)a.N * a.H * a.W;
+    const int64_t n0 = px * a.ld0 * ESZ, n1 = px * a.ld1 * ESZ, nw = (int64_t)a.coutT * a.K * ESZ;
+    if (n0 >= lim || n1 >= lim || nw >= lim) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrec1 = (uint32_t)n1;
+    g.nrecw = (uint32_t)nw;
+    g.bias0 = g.bias1 = 0;
+    return true;
+}
+
+template <typename T>
+static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    TilePlan t;
+    t.kind = 0;
+    t.bm = t.bn = 0;
+    t.splitk = 0;
+    const int hp = (hint / 100000000) % 10;
+    const int hs = (hint / 1000000) % 100, hbm = (hint / 1000) % 1000, hbn = hint % 1000;
     const int m1 = a.Ho * a.Wo;  // rows of one image
     auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(m1, m) * vt_cdiv(a.coutT, n); };
-    hint %= 1000000000;  // +1e9 = "register-staged kernel" flag, handled by dispatch()
-    if (hint > 0) {
-        bm = (hint / 1000) % 1000;
-        bn = hint % 1000;
-        splitk = hint / 1000000;
-    } else {
-        // keep >= ~2 workgroups per CU (256 CUs) where the problem allows it; measured on the
-        // frame's shapes (tools/conv_bench.py): 128x128 when M is large, 64x128 for mid M with
-        // wide N, 64x64 for the 64x64 / 32x32-pixel layers
-        bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
-        bm = 128;
-        if (bn == 128) {
+    auto ptiles = [&](int th, int n) {
+        return (int64_t)vt_cdiv(a.Ho, th) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, n);
+    };
+    GldsArgs g;
+    const bool can_patch = hp != 2 && patch_eligible<T>(a, g);
+    int units = 0;  // K units that can be split: K-steps (1-D) or channel chunks (patch)
+    if (hbm > 0) {
+        t.kind = hp == 1 ? 1 : 0;
+        t.bm = hbm;
+        t.bn = hbn;
+        t.splitk = hs;
+        if (t.kind == 1 && !can_patch) t.kind = 0, t.bm = 128, t.bn = hbn >= 64 ? hbn : 64;
+    } else if (can_patch) {
+        // measured on MI355X (tools/conv_bench.py): 256-pixel tiles with 8 waves when they still
+        // give every CU a workgroup, else 128-pixel tiles and split-K over channel chunks
+        t.kind = 1;
+        if (a.coutT <= 16) {
+            t.bm = 128, t.bn = 16;
+        } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
+            t.bm = 256, t.bn = 128;
+        } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
+            t.bm = 256, t.bn = 64;
+        } else if (a.coutT >= 64) {
+            t.bm = 128, t.bn = 64;
+        } else {
+            t.kind = 0;  // 17..63 output channels: no patch instance, use the 1-D kernels
+        }
+    }
+    if (t.kind == 0 && t.bm == 0) {
+        // 1-D tiles: keep >= ~2 workgroups per CU (256 CUs) where the problem allows it
+        t.bn = a.coutT <= 16 ? 16 : a.coutT <= 32 ? 32 : a.coutT <= 64 ? 64 : 128;
+        t.bm = 128;
+        if (t.bn == 128) {
             if (tiles(128, 128) < 512) {
-                bm = 64;
-                if (tiles(64, 128) < 512 && tiles(64, 64) >= 128) bn = 64;
+                t.bm = 64;
+                if (tiles(64, 128) < 512 && tiles(64, 64) >= 128) t.bn = 64;
             }
-        } else if (bn == 64) {
-            if (tiles(128, 64) < 512) bm = 64;
-        }
-        splitk = 0;
-    }
-    const int nk = vt_cdiv(a.K, bk);
-    if (splitk == 0) {
-        // too few tiles to fill 256 CUs: cut K so that ~512 workgroups exist, >= 2 K-steps each
-        splitk = 1;
-        const int64_t t = tiles(bm, bn);
-        if (t < 384 && nk >= 4) {
-            int64_t s = (512 + t - 1) / t;
-            if (s > nk / 2) s = nk / 2;
-            if (s > 32) s = 32;
-            splitk = (int)s;
+        } else if (t.bn == 64) {
+            if (tiles(128, 64) < 512) t.bm = 64;
         }
     }
-    if (splitk > 1) {
-        const int64_t need = (int64_t)splitk * a.M * ((a.coutT + 7) / 8 * 8);
-        if (!a.partial || need > ws_floats_avail) splitk = 1;  // no workspace: single pass
+    int64_t ntiles;
+    if (t.kind == 1) {
+        units = a.cin / BK;
+        ntiles = ptiles(t.bm / 16, t.bn);
+    } else {
+        units = vt_cdiv(a.K, BK);
+        ntiles = tiles(t.bm, t.bn);
     }
-    if (splitk < 1) splitk = 1;
+    if (t.splitk == 0) {
+        // too few tiles to fill 256 CUs: cut K so that ~512 workgroups exist
+        t.splitk = 1;
+        const int min_units = t.kind == 1 ? 1 : 2;
+        if (ntiles < 384 && units >= 2 * min_units) {
+            int64_t sk = (512 + ntiles - 1) / ntiles;
+            if (sk > units / min_units) sk = units / min_units;
+            if (sk > 32) sk = 32;
+            t.splitk = (int)sk;
+        }
+    }
+    if (t.splitk > units) t.splitk = units;
+    if (t.splitk > 1) {
+        const int64_t need = (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8);
+        if (!a.partial || need > ws_floats_avail) t.splitk = 1;  // no workspace: single pass
+    }
+    if (t.splitk < 1) t.splitk = 1;
+    // normalise so that no slice is empty (what the launch will use)
+    const int per = vt_cdiv(units, t.splitk);
+    t.splitk = vt_cdiv(units, per);
+    return t;
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int DIL>
+int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    ConvArgs args = a;
+    args.tiles_n = vt_cdiv(a.coutT, BN);
+    args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
+    const int units = a.cin / BK;
+    args.kps = vt_cdiv(units, args.splitk);
+    args.splitk = vt_cdiv(units, args.kps);
+    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n * args.splitk;
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+    int rc = vt_check_launch("vt_conv2d(patch)");
+    if (rc != VT_OK || args.splitk == 1) return rc;
+    int64_t rb = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
+    if (rb > 4096) rb = 4096;
+    VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), stream, args);
+    return vt_check_launch("vt_conv2d(split-K reduce)");
 }
 
 template <typename T>
 int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) {
-    int bm = 0, bn = 0, sk = 1;
-    constexpr int BK = 8 * (16 / (int)sizeof(T));
-    choose_tile(a0, hint, (int)(ws_floats > 0x7fffffff ? 0x7fffffff : ws_floats), BK, bm, bn, sk);
     ConvArgs a = a0;
     a.force_generic = hint >= 1000000000;
-    a.splitk = sk;
+    const TilePlan t = choose_plan<T>(a, hint % 1000000000, ws_floats);
+    a.splitk = t.splitk;
     a.ldp = (a.coutT + 7) / 8 * 8;
+    if (t.kind == 1) {
+        GldsArgs g;
+        if (!patch_eligible<T>(a, g)) {
+            vt_set_error("vt_conv2d: patch kernel requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+#define VT_PATCH(TH_, BN_, WM_, WN_, DIL_) \
+    if (t.bm == TH_ * 16 && t.bn == BN_ && a.dil == DIL_) return launch_patch<T, TH_, BN_, WM_, WN_, DIL_>(a, g, stream);
+        VT_PATCH(16, 128, 4, 2, 1)
+        VT_PATCH(16, 64, 4, 2, 1)
+        VT_PATCH(8, 64, 2, 2, 1)
+        VT_PATCH(8, 64, 2, 2, 2)
+        VT_PATCH(8, 64, 2, 2, 4)
+        VT_PATCH(8, 16, 4, 1, 1)
+        VT_PATCH(8, 16, 4, 1, 2)
+        VT_PATCH(8, 16, 4, 1, 4)
+#undef VT_PATCH
+        vt_set_error("vt_conv2d: no compiled patch tile %dx%d dil %d", t.bm, t.bn, a.dil);
+        return VT_ERR_UNSUPPORTED;
+    }
+    const int bm = t.bm, bn = t.bn;
 #define VT_CFG(M_, N_, WM_, WN_) \
     if (bm == M_ && bn == N_) return launch_cfg<T, M_, N_, WM_, WN_>(a, stream);
     VT_CFG(128, 128, 2, 2)
@@ -886,23 +1187,24 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
 extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    int bm = 0, bn = 0, sk = 1;
-    const int bk = d->dtype == VT_BF16 ? 64 : 32;
+    a.force_generic = d->tile_hint >= 1000000000;
     const int64_t wsf = d->splitk_ws ? d->splitk_ws_bytes / 4 : 0;
-    choose_tile(a, d->tile_hint, (int)(wsf > 0x7fffffff ? 0x7fffffff : wsf), bk, bm, bn, sk);
-    return sk * 1000000 + bm * 1000 + bn;
+    const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
+                                           : choose_plan<float>(a, d->tile_hint % 1000000000, wsf);
+    return t.kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
 }
 
 extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    int bm = 0, bn = 0, sk = 1;
-    const int bk = d->dtype == VT_BF16 ? 64 : 32;
+    a.force_generic = d->tile_hint >= 1000000000;
     float dummy;
     a.partial = &dummy;  // "a workspace of any size exists": report what the heuristic would use
-    choose_tile(a, d->tile_hint, 0x7fffffff, bk, bm, bn, sk);
-    if (sk <= 1) return 0;
-    return (int64_t)sk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
+    const int64_t big = (int64_t)1 << 40;
+    const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, big)
+                                           : choose_plan<float>(a, d->tile_hint % 1000000000, big);
+    if (t.splitk <= 1) return 0;
+    return (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
 }
 
 // ---------------------------------------------------------------------------------

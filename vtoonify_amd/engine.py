@@ -498,8 +498,9 @@ class VToonifyEngine:
             tile = self.lib.vt_conv2d_tile(C.byref(d))
             if tile < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
-            sk, bm, bn = tile // 1000000, (tile // 1000) % 1000, tile % 1000
-            info["kernel"] = f"conv_igemm<{tname},{bm}x{bn}>" + (f"+splitk{sk}" if sk > 1 else "")
+            kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
+            kname = "conv_patch" if kind == 1 else "conv_igemm"
+            info["kernel"] = f"{kname}<{tname},{bm}x{bn}>" + (f"+splitk{sk}" if sk > 1 else "")
             info["splitk"] = sk
 
     # ------------------------------------------------------------------ public API
