@@ -27,6 +27,8 @@
 // epilogue (bias, LeakyReLU / relu-tanh, gain, style-degree scaling, residual add,
 // pixel-shuffle for the polyphase up-sampling conv, NHWC or planar NCHW stores) runs
 // from an LDS-staged fp32 tile so every global store is a full 16-byte vector.
+#include <stdlib.h>
+
 #include "vt_common.hpp"
 
 namespace {
@@ -200,83 +202,124 @@ struct PatchRows {    // 2-D tiles of TW-pixel rows (patch-resident kernel)
     }
 };
 
+// Four consecutive output columns n..n+3 of GEMM row m, finished (bias/activation/gain applied):
+// residual add, pixel shuffle of the polyphase form, NHWC (8/16-byte store) or planar NCHW.
+__device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, float* f) {
+    const int HoWo = p.Ho * p.Wo;
+    if (p.out_layout == VT_OUT_NHWC) {
+        int64_t opix = m;
+        int co = n;
+        if (p.phases > 1) {
+            const int ph = n / p.cout;
+            co = n - ph * p.cout;
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            opix = ((int64_t)img * (2 * p.Ho) + 2 * oy + (ph >> 1)) * (2 * p.Wo) + 2 * ox + (ph & 1);
+        }
+        const int lim = (p.phases > 1) ? p.cout : p.coutT;
+        const int nvalid = (lim - co) < 4 ? (lim - co) : 4;
+        if (p.out_f32) {
+            float* o = (float*)p.out + opix * p.ld_out + co;
+            const float* rs = p.resid ? (const float*)p.resid + opix * p.ld_res + co : nullptr;
+            if (p.vec_store && nvalid == 4) {
+                if (rs) {
+                    float g[4];
+                    unpack16<float>(ld128(rs), g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] += p.beta * g[i];
+                }
+                st128(o, pack16<float>(f));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nvalid) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
+            }
+        } else {
+            bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
+            const bf16_t* rs = p.resid ? (const bf16_t*)p.resid + opix * p.ld_res + co : nullptr;
+            if (p.vec_store && nvalid == 4) {
+                if (rs) {
+                    const u64v r = *reinterpret_cast<const u64v*>(rs);
+                    f[0] += p.beta * vt_u2f(r.x << 16);
+                    f[1] += p.beta * vt_u2f(r.x & 0xffff0000u);
+                    f[2] += p.beta * vt_u2f(r.y << 16);
+                    f[3] += p.beta * vt_u2f(r.y & 0xffff0000u);
+                }
+                u64v v;
+                v.x = pack_bf16x2(f[0], f[1]);
+                v.y = pack_bf16x2(f[2], f[3]);
+                *reinterpret_cast<u64v*>(o) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nvalid) o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
+            }
+        }
+    } else {
+        // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
+        float* o = (float*)p.out;
+        const float* rs = (const float*)p.resid;
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (n + i >= p.coutT) break;
+            const int64_t off = ((int64_t)img * p.cout + n + i) * HoWo + rem;
+            o[off] = f[i] + (rs ? p.beta * rs[off] : 0.0f);
+        }
+    }
+}
+
+// Epilogue straight from the accumulators.  The kernels issue the MFMAs with the operands
+// swapped (weights as the "A" matrix, pixels as "B"), so the C/D fragment of lane (q, l15) holds
+// FOUR CONSECUTIVE OUTPUT CHANNELS (4q..4q+3) of ONE pixel (l15): bias, activation, residual and
+// the store are done in registers -- 8-byte bf16 / 16-byte fp32 vectors per lane, no LDS staging
+// pass, no barriers.  (The LDS-staged epilogue this replaces cost 12 us of a 34 us launch.)
 template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
-                                              unsigned char* smem, const RowMap rowmap, int n0, int split) {
+                                              unsigned char* /*smem*/, const RowMap rowmap, int n0, int split) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int SROWS = WM * 16, SLD = BN + 4;
-    constexpr int NT = WM * WN * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, l15 = lane & 15;
-    const int HoWo = p.Ho * p.Wo;
     // ---- split-K: raw accumulators to the fp32 workspace, conv_splitk_reduce finishes ---
     if (p.splitk > 1) {
         float* part = p.partial + (int64_t)split * p.M * p.ldp;
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a) {
+            const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + b * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = rowmap(wm * (TM * 16) + a * 16 + q * 4 + r);
-                    if (m >= 0 && n < p.ldp) part[(int64_t)m * p.ldp + n] = acc[a][b][r];
+                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
+                if (m >= 0 && n < p.ldp) {
+                    float f[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                    st128(part + (int64_t)m * p.ldp + n, pack16<float>(f));
                 }
             }
+        }
         return;
     }
-
-    // ---- epilogue -----------------------------------------------------------------
-    float* stage = reinterpret_cast<float*>(smem);
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
 #pragma unroll
-    for (int pass = 0; pass < TM; ++pass) {
-        if (pass > 0) __syncthreads();
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
+        float bv[4];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int colb = wn * (TN * 16) + b * 16;
-            const int n = n0 + colb + l15;
-            const int co = (p.phases > 1) ? n % p.cout : n;
-            const float bv = (p.bias && n < p.coutT) ? p.bias[co] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                stage[(wm * 16 + q * 4 + r) * SLD + colb + l15] = conv_finish(p, acc[pass][b][r], bv, ga);
+        for (int i = 0; i < 4; ++i) {
+            const int nn = n + i;
+            const int co = (p.phases > 1) ? nn % p.cout : nn;
+            bv[i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
         }
-        __syncthreads();
-        if (p.out_layout == VT_OUT_NHWC) {
-            constexpr int CV = BN / 8;
-            for (int idx = tid; idx < SROWS * CV; idx += NT) {
-                const int row_l = idx / CV, cv = idx - row_l * CV;
-                const int m = rowmap((row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15));
-                const int n = n0 + cv * 8;
-                if (m < 0 || n >= p.coutT) continue;
-                float f[8];
-                {
-                    const u128 lo = ld128(stage + row_l * SLD + cv * 8);
-                    const u128 hi = ld128(stage + row_l * SLD + cv * 8 + 4);
-                    unpack16<float>(lo, f);
-                    unpack16<float>(hi, f + 4);
-                }
-                store_nhwc8(p, m, n, f);
-            }
-        } else {
-            // planar NCHW fp32 (small cout: ToRGB, fusion_skip, masks; generic op surface)
-            float* o = (float*)p.out;
-            const float* rs = (const float*)p.resid;
-            for (int idx = tid; idx < SROWS * BN; idx += NT) {
-                const int col = idx / SROWS, row_l = idx - col * SROWS;
-                const int m = rowmap((row_l >> 4) * (TM * 16) + pass * 16 + (row_l & 15));
-                const int n = n0 + col;
-                if (m < 0 || n >= p.coutT) continue;
-                const int img = m / HoWo;
-                const int rem = m - img * HoWo;
-                const int64_t off = ((int64_t)img * p.cout + n) * HoWo + rem;
-                float v = stage[row_l * SLD + col];
-                if (rs) v += p.beta * rs[off];
-                o[off] = v;
-            }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+            if (m < 0 || n >= p.coutT) continue;
+            float f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, acc[a][b][i], bv[i], ga);
+            store_out4(p, m, n, f);
         }
     }
 }
@@ -435,7 +478,7 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
@@ -470,7 +513,7 @@ struct GldsArgs {
     uint32_t bias0, bias1;          // bytes the source bases are moved back by ((pad*W+pad) pixels)
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NST>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int DBG = 0>
 __global__ void __launch_bounds__(256)
 conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
@@ -536,13 +579,14 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     // K-step state (all wave-uniform); `tap`/`kc` describe the NEXT step to be issued
     const int nk_all = p.K / BK;
     const int kt0 = split * p.kps;
-    const int kt1 = (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;
+    const int kt1 = (DBG == 3 || DBG == 5) ? kt0 + 1 : (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;  // DBG 3: one K-step
     int tap = (kt0 * BK) / p.cin;
     int kc = kt0 * BK - tap * p.cin;   // channel offset inside the concatenated input
     int seg_tap = -1, seg_src = -1;
     uint32_t soff_a = 0;               // byte offset of (tap, first channel of the source)
 
     auto issue = [&](int kt, int buf) {
+        if (DBG == 2) return;  // ablation: no global->LDS traffic
         const int src = (kc >= p.c0) ? 1 : 0;
         if (tap != seg_tap || src != seg_src) {   // uniform: new tap or new source
             seg_tap = tap;
@@ -615,7 +659,10 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+                for (int b = 0; b < TN; ++b) {
+                    if (DBG == 1) acc[a][b][0] += vt_u2f(fa[a].x ^ fb[b].x);  // ablation: LDS reads kept, no MFMA
+                    else Mma<T>::run(acc[a][b], fb[b], fa[a]);
+                }
         }
         // step kt+1 must have landed (in every wave) before anyone reads it; step kt's buffer may
         // be overwritten by the next issue once every wave has finished reading it
@@ -625,6 +672,13 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
         nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
     }
     __syncthreads();
+    if (DBG == 4 || DBG == 5) {  // ablation: no epilogue (4) / one K-step and no epilogue (5)
+        float sacc = 0.f;
+        for (int a = 0; a < TM; ++a)
+            for (int b = 0; b < TN; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
+        return;
+    }
     conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split);
 }
 
@@ -772,7 +826,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
         }
         // Before step s+1 is read: its weights (issued in step s-1) must have landed, and -- at a
         // chunk boundary -- the next patch.  Loads younger than B(s+1): the patch issued in step
@@ -903,8 +957,26 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         // (128x128: 2 stages; 128x64 / 64x128: 3; 64x64 and smaller: 4)
         constexpr int STAGE = ((BM + 31) / 32 + (BN + 31) / 32) * 32 * 128;
         constexpr int NST = STAGE * 4 <= 80 * 1024 ? 4 : STAGE * 3 <= 80 * 1024 ? 3 : 2;
-        auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST>;
-        VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        const char* dbg = getenv("VT_CONV_ABLATE");  // tools/conv_bench.py ablations only
+        if (BM == 128 && BN == 128 && dbg && dbg[0] == '1') {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 1 : 0>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '2') {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 2 : 0>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '3') {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 3 : 0>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '4') {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 4 : 0>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '5') {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 5 : 0>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        } else {
+            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST>;
+            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+        }
     } else {
         auto k = conv_igemm_kernel<T, BM, BN, WM, WN>;
         VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);

@@ -162,13 +162,24 @@ __device__ __forceinline__ u128 pack16<float>(const float* f) {
     v.w = vt_f2u(f[3]);
     return v;
 }
+// two fp32 -> packed bf16 pair, round-to-nearest-even (one v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef VT_EMU
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+#else
+    typedef __bf16 vt_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float vt_f32x2 __attribute__((ext_vector_type(2)));
+    const vt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_bf16x2));
+#endif
+}
 template <>
 __device__ __forceinline__ u128 pack16<bf16_t>(const float* f) {
     u128 v;
-    v.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-    v.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
-    v.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
-    v.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    v.x = pack_bf16x2(f[0], f[1]);
+    v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]);
+    v.w = pack_bf16x2(f[6], f[7]);
     return v;
 }
 
