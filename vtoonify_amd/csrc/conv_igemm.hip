@@ -1047,7 +1047,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         t.bn = hbn;
         t.splitk = hs;
         if (t.kind == 1 && !can_patch) t.kind = 0, t.bm = 128, t.bn = hbn >= 64 ? hbn : 64;
-    } else if (can_patch) {
+    } else if (can_patch && a.dil == 1) {   // dilated patches (trunk) measured slower than the 1-D kernel
         // measured on MI355X (tools/conv_bench.py): 256-pixel tiles with 8 waves when they still
         // give every CU a workgroup, else 128-pixel tiles and split-K over channel chunks
         t.kind = 1;
@@ -1088,7 +1088,8 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         // too few tiles to fill 256 CUs: cut K so that ~512 workgroups exist
         t.splitk = 1;
         const int min_units = t.kind == 1 ? 1 : 2;
-        if (ntiles < 384 && units >= 2 * min_units) {
+        const int64_t enough = t.kind == 1 && t.bm == 256 ? 192 : 384;  // 8-wave tiles: 1 WG fills a CU
+        if (ntiles < enough && units >= 2 * min_units) {
             int64_t sk = (512 + ntiles - 1) / ntiles;
             if (sk > units / min_units) sk = units / min_units;
             if (sk > 32) sk = 32;
