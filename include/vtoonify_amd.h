@@ -126,10 +126,12 @@ typedef struct vt_conv_desc {
     int32_t tile_hint;     /* 0 = auto; otherwise SPLITK*1000000 + BM*1000 + BN of a compiled tile
                               (SPLITK 0 = auto); +1000000000 forces the register-staged
                               loader where the direct-to-LDS one would apply */
-    void* splitk_ws;       /* optional fp32 workspace for split-K (NULL: never split).  Small-M /  */
+    void* splitk_ws;       /* optional workspace for split-K (NULL: never split).  Its first 16 KiB are
+                              per-tile arrival counters and MUST be zero before the first launch
+                              (every launch leaves them zero).  Small-M /                            */
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
-                              as separate workgroups and are summed in slice order by a second
-                              kernel; vt_conv2d_ws_bytes() says how much the heuristic wants */
+                              as separate workgroups; the last slice to arrive sums all slices in
+                              slice order (deterministic) and runs the epilogue; vt_conv2d_ws_bytes() says how much the heuristic wants */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);

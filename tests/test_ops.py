@@ -239,8 +239,10 @@ def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
     L = K.ACT_LRELU
     # patch kernel, auto plan (small image => 128x64 tiles + split-K over channel chunks)
     assert _conv_case(dev, dtype, 2, 128, 19, 37, 64, 3, 1, 1, 1, act=L, resid=True, ws=True, expect_kind=1) < t
-    assert _conv_case(dev, dtype, 1, 64, 9, 21, 72, 3, 1, 2, 2, act=L, ws=True, expect_kind=1) < t     # dil 2
-    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=1) < t          # dil 4
+    # dilated convs run the 1-D kernel by default (measured faster); the patch instances are forced
+    assert _conv_case(dev, dtype, 1, 64, 9, 21, 72, 3, 1, 2, 2, act=L, ws=True, hint=P + 128064, expect_kind=1) < t
+    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, hint=P + 128064, expect_kind=1) < t
+    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=0) < t
     assert _conv_case(dev, dtype, 1, 192, 8, 8, 1, 3, 1, 1, 1, act=K.ACT_RELU_TANH, planar=True, ws=True,
                       expect_kind=1) < t                                                               # mask conv
     # every compiled patch tile, forced by hint (S=0: auto split; S=2 forced)
@@ -274,6 +276,32 @@ def test_conv_batch_invariance(dev):
     yb = run(x)
     for i in range(3):
         assert torch.equal(yb[i:i + 1], run(x[i:i + 1])), i
+
+
+def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
+    """The last-arriving K-slice reduces in slice order: same bits as the separate reduce kernel,
+    run after run (the arrival counters re-arm themselves)."""
+    g = np.random.default_rng(9)
+    x = g.standard_normal((1, 256, 8, 8)).astype(np.float32)
+    w = (g.standard_normal((72, 256, 3, 3)) / 40).astype(np.float32)
+    wp = K.pack_conv_weight(T(w, dev), out_dtype=torch.bfloat16)
+    xt = K.nchw_to_nhwc(T(x, dev), torch.bfloat16)
+    ws = torch.zeros(4 << 20, dtype=torch.float32, device=dev)
+
+    def run(hint):
+        out = torch.zeros((1, 8, 8, 72), dtype=torch.bfloat16, device=dev)
+        K.conv2d(src0=xt, c0=256, ld0=256, n=1, h=8, w=8, out_h=8, out_w=8, weight=wp, cout=72, kh=3, kw=3, pad=1,
+                 act=K.ACT_LRELU, out=out, ld_out=72, dtype=K.VT_BF16, splitk_ws=ws, tile_hint=hint)
+        return out
+
+    for hint in (2 * P + 4000000 + 64064, P + 4000000 + 128064):
+        a = run(hint)
+        assert torch.equal(run(hint), a)          # counters re-armed, deterministic
+        monkeypatch.setenv("VT_SPLITK_TWO_PASS", "1")
+        b = run(hint)
+        monkeypatch.delenv("VT_SPLITK_TWO_PASS")
+        assert torch.equal(a, b), hint
+        assert int(ws.view(torch.int32)[:4096].abs().max()) == 0   # ticket area left zero
 
 
 def test_conv_concat_prologue_transposed(dev):

@@ -67,7 +67,7 @@ def main():
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esz = 2 if dt == torch.bfloat16 else 4
-    ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(512 << 20, dtype=torch.uint8, device=dev)
     lib = _lib.lib()
     import ctypes as C
     tot = 0.0

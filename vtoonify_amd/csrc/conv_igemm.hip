@@ -40,6 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #endif
 
+constexpr int64_t VT_TICKET_BYTES = 16384;  // split-K arrival counters at the head of the workspace: 4096 tiles
+
 struct ConvArgs {
     const void* src0;
     const void* src1;
@@ -62,6 +64,7 @@ struct ConvArgs {
     // writes raw fp32 accumulators to partial[s][m][ldp] and conv_splitk_reduce finishes.
     int splitk, kps, ldp;
     float* partial;
+    int* tickets;       // per-tile arrival counters (zero between launches) or NULL = two-pass split-K
     int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
 };
 
@@ -278,15 +281,17 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
 // pass, no barriers.  (The LDS-staged epilogue this replaces cost 12 us of a 34 us launch.)
 template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
-                                              unsigned char* /*smem*/, const RowMap rowmap, int n0, int split) {
+                                              unsigned char* smem, const RowMap rowmap, int n0, int split,
+                                              int tile_id) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, l15 = lane & 15;
-    // ---- split-K: raw accumulators to the fp32 workspace, conv_splitk_reduce finishes ---
+    // ---- split-K: every slice writes its raw fp32 accumulators to the workspace ----------
     if (p.splitk > 1) {
-        float* part = p.partial + (int64_t)split * p.M * p.ldp;
+        const int64_t slab = (int64_t)p.M * p.ldp;
+        float* part = p.partial + (int64_t)split * slab;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
@@ -299,7 +304,49 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                 }
             }
         }
-        return;
+        if (!p.tickets) return;  // two-pass mode: conv_splitk_reduce_kernel finishes
+        // In-launch reduction: the slice that arrives LAST at the tile's ticket counter sums all
+        // slabs (in slice order 0..S-1 -> deterministic whichever slice that is) and runs the
+        // normal epilogue.  Publish: plain stores -> drain -> barrier -> one agent-scope release
+        // -> relaxed ticket; consume: agent-scope acquire by one lane -> barrier -> plain loads.
+        vt_drain_vmem();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);  // the K loop is done with the tile buffers
+        int* ticket = p.tickets + tile_id;
+        if (tid == 0) {
+            vt_release_agent();
+            const int t = vt_ticket_add(ticket, 1);
+            const int last = (t == p.splitk - 1);
+            if (last) {
+                vt_acquire_agent();
+                vt_ticket_store(ticket, 0);  // re-arm for the next launch (all slices have arrived)
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
+                float f[4] = {0.f, 0.f, 0.f, 0.f};
+                if (m >= 0 && n < p.ldp) {
+                    const float* src = p.partial + (int64_t)m * p.ldp + n;
+                    unpack16<float>(ld128(src), f);
+                    for (int s = 1; s < p.splitk; ++s) {
+                        float g[4];
+                        unpack16<float>(ld128(src + s * slab), g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) f[i] += g[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[a][b][i] = f[i];
+            }
+        }
+        // fall through to the fused epilogue below
     }
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
 #pragma unroll
@@ -484,7 +531,7 @@ conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split, tile_n * p.tiles_m + tile_m);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -679,7 +726,7 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
         if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
         return;
     }
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split, tile_n * p.tiles_m + tile_m);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -849,7 +896,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
         }
     }
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split, tile_n * p.tiles_m + tile_m);
 }
 
 // Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
@@ -930,6 +977,15 @@ static bool glds_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
+// split-K finishing mode: in-launch (last-arriving slice reduces; needs the ticket area) unless the
+// tile count exceeds the ticket area or VT_SPLITK_TWO_PASS=1 asks for the separate reduce kernel
+// (A/B measurements, tests).
+static void split_mode(ConvArgs& args) {
+    const int64_t ntile = (int64_t)args.tiles_m * args.tiles_n;
+    const char* two = getenv("VT_SPLITK_TWO_PASS");
+    if (args.splitk <= 1 || ntile * 4 > VT_TICKET_BYTES || (two && two[0] == '1')) args.tickets = nullptr;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvArgs& a, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -945,6 +1001,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         args.splitk = 1;
         args.kps = nk;
     }
+    split_mode(args);
     const int64_t tiles = (int64_t)vt_cdiv(a.M, BM) * args.tiles_n * args.splitk;
     if (tiles >= ((int64_t)1 << 31)) {
         vt_set_error("vt_conv2d: too many tiles");
@@ -982,7 +1039,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
     }
     int rc = vt_check_launch("vt_conv2d");
-    if (rc != VT_OK || args.splitk == 1) return rc;
+    if (rc != VT_OK || args.splitk == 1 || args.tickets) return rc;
     int64_t blocks = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), stream, args);
@@ -1117,6 +1174,7 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     const int units = a.cin / BK;
     args.kps = vt_cdiv(units, args.splitk);
     args.splitk = vt_cdiv(units, args.kps);
+    split_mode(args);
     const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n * args.splitk;
     if (blocks >= ((int64_t)1 << 31)) {
         vt_set_error("vt_conv2d: too many tiles");
@@ -1125,7 +1183,7 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
     int rc = vt_check_launch("vt_conv2d(patch)");
-    if (rc != VT_OK || args.splitk == 1) return rc;
+    if (rc != VT_OK || args.splitk == 1 || args.tickets) return rc;
     int64_t rb = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
     if (rb > 4096) rb = 4096;
     VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), stream, args);
@@ -1241,7 +1299,10 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.out_f32 = d->out_dtype == VT_F32;
     a.M = d->n * d->out_h * d->out_w;
     const int osz = a.out_f32 ? 4 : 2;
-    a.partial = (float*)d->splitk_ws;
+    // workspace layout: [0, VT_TICKET_BYTES) per-tile arrival counters (must be zero when a launch
+    // starts; every launch leaves them zero), fp32 slabs after
+    a.tickets = d->splitk_ws ? (int*)d->splitk_ws : nullptr;
+    a.partial = d->splitk_ws ? (float*)((char*)d->splitk_ws + VT_TICKET_BYTES) : nullptr;
     a.vec_store = (d->out_layout == VT_OUT_NHWC) && ((uintptr_t)d->out % 16 == 0) &&
                   ((int64_t)d->ld_out * osz % 16 == 0) && (d->cout % 8 == 0) &&
                   (!d->resid || (((uintptr_t)d->resid % 16 == 0) && ((int64_t)d->ld_res * osz % 16 == 0)));
@@ -1252,7 +1313,7 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
     ConvArgs a;
     const int rc = fill_args(d, a);
     if (rc != VT_OK) return rc;
-    const int64_t wsf = d->splitk_ws ? d->splitk_ws_bytes / 4 : 0;
+    const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, wsf, stream);
     return dispatch<float>(a, d->tile_hint, wsf, stream);
 }
@@ -1261,7 +1322,7 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
     a.force_generic = d->tile_hint >= 1000000000;
-    const int64_t wsf = d->splitk_ws ? d->splitk_ws_bytes / 4 : 0;
+    const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, wsf);
     return t.kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
@@ -1277,7 +1338,7 @@ extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, big)
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, big);
     if (t.splitk <= 1) return 0;
-    return (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
+    return VT_TICKET_BYTES + (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
 }
 
 // ---------------------------------------------------------------------------------

@@ -189,6 +189,32 @@ __device__ __forceinline__ u128 pack16<bf16_t>(const float* f) {
 //   to lds_wave_base + lane*16; bytes at or beyond `nrec` read as ZERO (range check is on
 //   voff + soff).  The emulation build reproduces exactly that.
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// inter-workgroup hand-off (split-K arrival counter): agent-scope release / acquire + a relaxed
+// agent-scope ticket, exactly the placement-independent protocol of cdna_hip_programming.md
+// section 5 ("in-launch split-K reduction") / section 6 Guideline 16.
+// ---------------------------------------------------------------------------------
+#ifdef VT_EMU
+static inline void vt_release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
+static inline void vt_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+static inline void vt_drain_vmem() {}
+static inline int vt_ticket_add(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+static inline void vt_ticket_store(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+#else
+__device__ __forceinline__ void vt_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void vt_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    vt_drain_vmem();  // restate the post-write-back wait where the compiler cannot drop it (ROCm 7.2)
+}
+__device__ __forceinline__ void vt_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ int vt_ticket_add(int* p, int v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vt_ticket_store(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 #ifdef VT_EMU
 struct BufRsrc {
     const char* base;

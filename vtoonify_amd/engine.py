@@ -490,7 +490,10 @@ class VToonifyEngine:
             if b < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
             need = max(need, b)
-        ws = self._buf(plan, "splitk_ws", (max(need, 16),), torch.uint8) if need else None
+        ws = None
+        if need:  # zero-filled: the head of the workspace holds the split-K arrival counters
+            ws = torch.zeros((need,), dtype=torch.uint8, device=self.device)
+            plan.bufs["splitk_ws"] = ws
         tname = "bf16" if self.dt == K.VT_BF16 else "f32"
         for d, info in plan.convs:
             if ws is not None:
