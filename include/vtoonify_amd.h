@@ -130,8 +130,8 @@ typedef struct vt_conv_desc {
                               per-tile arrival counters and MUST be zero before the first launch
                               (every launch leaves them zero).  Small-M /                            */
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
-                              as separate workgroups; the last slice to arrive sums all slices in
-                              slice order (deterministic) and runs the epilogue; vt_conv2d_ws_bytes() says how much the heuristic wants */
+                              as separate workgroups and are summed in slice order (deterministic) by a
+                              second kernel (or by the last slice to arrive, VT_SPLITK_IN_LAUNCH=1); vt_conv2d_ws_bytes() says how much the heuristic wants */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);

@@ -295,11 +295,11 @@ def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
         return out
 
     for hint in (2 * P + 4000000 + 64064, P + 4000000 + 128064):
+        b = run(hint)                             # default: separate reduce kernel
+        monkeypatch.setenv("VT_SPLITK_IN_LAUNCH", "1")
         a = run(hint)
         assert torch.equal(run(hint), a)          # counters re-armed, deterministic
-        monkeypatch.setenv("VT_SPLITK_TWO_PASS", "1")
-        b = run(hint)
-        monkeypatch.delenv("VT_SPLITK_TWO_PASS")
+        monkeypatch.delenv("VT_SPLITK_IN_LAUNCH")
         assert torch.equal(a, b), hint
         assert int(ws.view(torch.int32)[:4096].abs().max()) == 0   # ticket area left zero
 

@@ -977,13 +977,15 @@ static bool glds_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
-// split-K finishing mode: in-launch (last-arriving slice reduces; needs the ticket area) unless the
-// tile count exceeds the ticket area or VT_SPLITK_TWO_PASS=1 asks for the separate reduce kernel
-// (A/B measurements, tests).
+// split-K finishing mode.  Default: the separate conv_splitk_reduce_kernel (6 us per conv).  The
+// in-launch form (last-arriving slice reduces, VT_SPLITK_IN_LAUNCH=1) is correct and deterministic
+// but measured 2x SLOWER on MI355X for these shapes (64-128 KB of slabs per tile: the per-workgroup
+// agent-scope release writes back the XCD's dirty L2 lines, ~6 us each, serialised per CU) -- kept
+// for A/B runs and for shapes with tiny slabs.
 static void split_mode(ConvArgs& args) {
     const int64_t ntile = (int64_t)args.tiles_m * args.tiles_n;
-    const char* two = getenv("VT_SPLITK_TWO_PASS");
-    if (args.splitk <= 1 || ntile * 4 > VT_TICKET_BYTES || (two && two[0] == '1')) args.tickets = nullptr;
+    const char* inl = getenv("VT_SPLITK_IN_LAUNCH");
+    if (args.splitk <= 1 || ntile * 4 > VT_TICKET_BYTES || !(inl && inl[0] == '1')) args.tickets = nullptr;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
