@@ -240,13 +240,15 @@ def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
     # patch kernel, auto plan (small image => 128x64 tiles + split-K over channel chunks)
     assert _conv_case(dev, dtype, 2, 128, 19, 37, 64, 3, 1, 1, 1, act=L, resid=True, ws=True, expect_kind=1) < t
     # dilated convs run the 1-D kernel by default (measured faster); the patch instances are forced
-    assert _conv_case(dev, dtype, 1, 64, 9, 21, 72, 3, 1, 2, 2, act=L, ws=True, hint=P + 128064, expect_kind=1) < t
-    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, hint=P + 128064, expect_kind=1) < t
-    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=0) < t
+    # dilated convs: deep-ring 128x128 patch instance, one channel chunk per K slice (the trunk)
+    assert _conv_case(dev, dtype, 1, 128, 9, 21, 136, 3, 1, 2, 2, act=L, ws=True, expect_kind=1) < t
+    assert _conv_case(dev, dtype, 2, 128, 11, 17, 128, 3, 1, 4, 4, resid=True, ws=True, expect_kind=1) < t
+    assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=0) < t   # cout 64: 1-D
     assert _conv_case(dev, dtype, 1, 192, 8, 8, 1, 3, 1, 1, 1, act=K.ACT_RELU_TANH, planar=True, ws=True,
                       expect_kind=1) < t                                                               # mask conv
     # every compiled patch tile, forced by hint (S=0: auto split; S=2 forced)
-    for hint in (P + 256128, P + 256064, P + 128064, P + 128016, P + 2000000 + 128064, P + 2000000 + 256128):
+    for hint in (P + 256128, P + 256064, P + 128064, P + 128016, P + 2000000 + 128064, P + 2000000 + 256128,
+                 P + 128128, P + 1000000 + 128128, P + 2000000 + 128128):
         assert _conv_case(dev, dtype, 1, 128, 21, 35, 136, 3, 1, 1, 1, act=L, hint=hint, resid=True, ws=True,
                           seed=hint % 97) < t, hint
     # 1-D direct-to-LDS kernels (patch disabled with P=2), incl. stride 2 and a 1x1 conv, with split-K

@@ -741,7 +741,33 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
 //   K order: [chunk][tap]  (same products as [tap][chunk], different fp32 summation order)
 //   split-K: slices are whole chunks.
 // ---------------------------------------------------------------------------------------
-template <typename T, int TH, int BN, int WM, int WN, int DIL>
+// counted-vmcnt selector: `ahead` weight steps (LB loads each) and optionally the next patch (PA
+// loads) may stay in flight
+template <int K, int LB, int PA>
+struct PatchWait {
+    static __device__ __forceinline__ void run(int ahead, bool a_out) {
+        if (ahead >= K) {
+            if (a_out) vt_glds_wait_n<K * LB + PA>();
+            else vt_glds_wait_n<K * LB>();
+        } else {
+            PatchWait<K - 1, LB, PA>::run(ahead, a_out);
+        }
+    }
+};
+template <int LB, int PA>
+struct PatchWait<0, LB, PA> {
+    static __device__ __forceinline__ void run(int, bool a_out) {
+        if (a_out) vt_glds_wait_n<PA>();
+        else vt_glds_wait_n<0>();
+    }
+};
+
+// NSTB = weight ring depth (NSTB-1 taps of weights in flight).  With a deep ring and one channel
+// chunk per K-slice (the 32x32-pixel trunk under split-K) a workgroup issues its patch and most of
+// its 9 weight tiles up front and waits for memory ONCE instead of once per tap.
+// ABUF = patch buffers: 2 = next chunk's patch prefetched during the current chunk; 1 = the slice
+// must be a single chunk (host-checked).
+template <typename T, int TH, int BN, int WM, int WN, int DIL, int NSTB, int ABUF>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int TW = 16;
@@ -755,17 +781,16 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch loads per wave per chunk
     constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
     constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
-    constexpr int NSTB = 3, JA = 3;
-    constexpr int SROWS = WM * 16, SLD = BN + 4;
+    constexpr int JA = 3;
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiling");
     static_assert(TM * WM == TH, "one 16-pixel tile row per MFMA row block");
-    static_assert(SROWS * SLD * 4 <= 2 * A_BYTES + NSTB * B_BYTES, "epilogue staging must fit");
-    static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(LB + PA < 64, "vmcnt is 6 bits");
+    static_assert(NSTB >= 3 && (ABUF == 1 || ABUF == 2), "ring depth / patch buffers");
+    static_assert(ABUF * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((NSTB - 2) * LB + PA < 64, "vmcnt is 6 bits");
 
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ABUF * A_BYTES + NSTB * B_BYTES];
     auto sA = [&](int b) -> unsigned char* { return smem + b * A_BYTES; };
-    auto sB = [&](int b) -> unsigned char* { return smem + 2 * A_BYTES + b * B_BYTES; };
+    auto sB = [&](int b) -> unsigned char* { return smem + ABUF * A_BYTES + b * B_BYTES; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -838,23 +863,26 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     const int b_row0 = wn * (TN * 16) + l15;
 
-    // prologue: patch of the first chunk + two weight steps in flight; patch and step 0 landed
+    // prologue: patch of the first chunk + NSTB-1 weight steps in flight; patch and step 0 landed
     issue_a(ch0, 0);
-    issue_b(0, 0);
-    if (nsteps > 1) {
-        issue_b(1, 1);
-        vt_glds_wait_n<LB>();
-    } else {
-        vt_glds_wait_n<0>();
-    }
+    int issued = 0;   // weight steps issued so far
+#pragma unroll
+    for (int s = 0; s < NSTB - 1; ++s)
+        if (issued < nsteps) {
+            issue_b(issued, s);
+            ++issued;
+        }
+    PatchWait<NSTB - 2, LB, PA>::run(issued - 1, false);
     vt_lds_barrier();
 
-    int abuf = 0, bbuf = 0, nbbuf = 2, tap = 0, chunk = ch0;
+    int abuf = 0, bbuf = 0, nbbuf = NSTB - 1, tap = 0, chunk = ch0;
     int a_age = 99;  // steps since the next chunk's patch was issued (99 = none in flight)
     for (int s = 0; s < nsteps; ++s) {
-        const bool more_b = s + 2 < nsteps;
-        if (more_b) issue_b(s + 2, nbbuf);
-        if (tap == JA && chunk + 1 < ch1) {
+        if (issued < nsteps) {
+            issue_b(issued, nbbuf);
+            ++issued;
+        }
+        if (ABUF == 2 && tap == JA && chunk + 1 < ch1) {
             issue_a(chunk + 1, abuf ^ 1);
             a_age = 0;
         }
@@ -875,15 +903,12 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
         }
-        // Before step s+1 is read: its weights (issued in step s-1) must have landed, and -- at a
-        // chunk boundary -- the next patch.  Loads younger than B(s+1): the patch issued in step
-        // s-1 or s, and B(s+2).
-        const bool b_out = more_b;
-        const bool a_out = a_age <= 1 && !(tap == 8);   // patch still allowed in flight
-        if (b_out && a_out) vt_glds_wait_n<LB + PA>();
-        else if (a_out) vt_glds_wait_n<PA>();
-        else if (b_out) vt_glds_wait_n<LB>();
-        else vt_glds_wait_n<0>();
+        // Before step s+1 is read its weights must have landed (and, at a chunk boundary, the next
+        // patch).  Loads younger than B(s+1): B(s+2..issued-1) and a patch issued in step s-1 or s
+        // (it is issued AFTER that step's weights).  Once the patch is two steps old it sits
+        // behind nothing that may stay outstanding, so the count below forces it to completion --
+        // JA + 2 < 9, i.e. always before the chunk ends.
+        PatchWait<NSTB - 2, LB, PA>::run(issued - 2 - s, a_age <= 1);
         vt_lds_barrier();
         if (a_age < 99) ++a_age;
         bbuf = (bbuf + 1 == NSTB) ? 0 : bbuf + 1;
@@ -891,7 +916,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
         if (++tap == 9) {
             tap = 0;
             ++chunk;
-            abuf ^= 1;
+            if (ABUF == 2) abuf ^= 1;
             a_age = 99;
         }
     }
@@ -1106,20 +1131,31 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         t.bn = hbn;
         t.splitk = hs;
         if (t.kind == 1 && !can_patch) t.kind = 0, t.bm = 128, t.bn = hbn >= 64 ? hbn : 64;
-    } else if (can_patch && a.dil == 1) {   // dilated patches (trunk) measured slower than the 1-D kernel
+    } else if (can_patch) {
         // measured on MI355X (tools/conv_bench.py): 256-pixel tiles with 8 waves when they still
-        // give every CU a workgroup, else 128-pixel tiles and split-K over channel chunks
+        // give every CU a workgroup; otherwise 128-pixel tiles.  Few tiles + wide N (the 32x32 /
+        // 64x64-pixel layers): 128x128 tiles with the deep weight ring and split-K over channel
+        // chunks, so a workgroup waits for memory once, not once per tap.
         t.kind = 1;
-        if (a.coutT <= 16) {
+        const int units_p = a.cin / BK;
+        if (a.dil == 1 && a.coutT <= 16) {
             t.bm = 128, t.bn = 16;
         } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
             t.bm = 256, t.bn = 128;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
             t.bm = 256, t.bn = 64;
-        } else if (a.coutT >= 64) {
+        } else if (a.coutT >= 128 && ptiles(8, 128) < 192 &&
+                   (a.dil == 1 || ptiles(8, 128) * units_p <= 1024)) {
+            t.bm = 128, t.bn = 128;
+            int64_t sk = (256 + ptiles(8, 128) - 1) / ptiles(8, 128);
+            if (sk > units_p || a.dil != 1) sk = units_p;   // dilated instances: one chunk per slice
+            if (sk > 32) sk = 32;
+            t.splitk = (int)sk;
+            if (a.dil != 1 && sk != units_p) t.kind = 0, t.bm = 0, t.splitk = 0;
+        } else if (a.dil == 1 && a.coutT >= 64) {
             t.bm = 128, t.bn = 64;
         } else {
-            t.kind = 0;  // 17..63 output channels: no patch instance, use the 1-D kernels
+            t.kind = 0;  // no patch instance for this shape: use the 1-D kernels
         }
     }
     if (t.kind == 0 && t.bm == 0) {
@@ -1167,7 +1203,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     return t;
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int DIL>
+template <typename T, int TH, int BN, int WM, int WN, int DIL, int NSTB, int ABUF>
 int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
@@ -1182,7 +1218,11 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL>;
+    if (ABUF == 1 && args.kps != 1) {
+        vt_set_error("vt_conv2d: single-buffer patch instance needs one chunk per K slice");
+        return VT_ERR_UNSUPPORTED;
+    }
+    auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL, NSTB, ABUF>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
     int rc = vt_check_launch("vt_conv2d(patch)");
     if (rc != VT_OK || args.splitk == 1 || args.tickets) return rc;
@@ -1205,16 +1245,20 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             vt_set_error("vt_conv2d: patch kernel requested for an ineligible convolution");
             return VT_ERR_UNSUPPORTED;
         }
-#define VT_PATCH(TH_, BN_, WM_, WN_, DIL_) \
-    if (t.bm == TH_ * 16 && t.bn == BN_ && a.dil == DIL_) return launch_patch<T, TH_, BN_, WM_, WN_, DIL_>(a, g, stream);
-        VT_PATCH(16, 128, 4, 2, 1)
-        VT_PATCH(16, 64, 4, 2, 1)
-        VT_PATCH(8, 64, 2, 2, 1)
-        VT_PATCH(8, 64, 2, 2, 2)
-        VT_PATCH(8, 64, 2, 2, 4)
-        VT_PATCH(8, 16, 4, 1, 1)
-        VT_PATCH(8, 16, 4, 1, 2)
-        VT_PATCH(8, 16, 4, 1, 4)
+        const int units = a.cin / (8 * (16 / (int)sizeof(T)));
+        const bool one_chunk = vt_cdiv(units, a.splitk) == 1;
+#define VT_PATCH(TH_, BN_, WM_, WN_, DIL_, NSTB_, ABUF_, COND_) \
+    if (t.bm == TH_ * 16 && t.bn == BN_ && a.dil == DIL_ && (COND_))  \
+        return launch_patch<T, TH_, BN_, WM_, WN_, DIL_, NSTB_, ABUF_>(a, g, stream);
+        VT_PATCH(16, 128, 4, 2, 1, 3, 2, true)
+        VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)
+        VT_PATCH(8, 64, 2, 2, 1, 3, 2, true)
+        VT_PATCH(8, 16, 4, 1, 1, 3, 2, true)
+        // deep weight ring (5 taps in flight): one chunk per slice = single patch buffer
+        VT_PATCH(8, 128, 2, 2, 1, 6, 1, one_chunk)
+        VT_PATCH(8, 128, 2, 2, 2, 6, 1, one_chunk)
+        VT_PATCH(8, 128, 2, 2, 4, 6, 1, one_chunk)
+        VT_PATCH(8, 128, 2, 2, 1, 6, 2, !one_chunk)
 #undef VT_PATCH
         vt_set_error("vt_conv2d: no compiled patch tile %dx%d dil %d", t.bm, t.bn, a.dil);
         return VT_ERR_UNSUPPORTED;
