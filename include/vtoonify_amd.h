@@ -132,10 +132,13 @@ typedef struct vt_conv_desc {
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
                               as separate workgroups and are summed in slice order (deterministic) by a
                               second kernel (or by the last slice to arrive, VT_SPLITK_IN_LAUNCH=1); vt_conv2d_ws_bytes() says how much the heuristic wants */
+    int32_t splitk_phase;  /* two-pass split-K only: 0 = slices + reduce (default), 1 = launch the K
+                              slices only, 2 = launch the reduce pass only (lets a caller time or
+                              schedule the two kernels separately) */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
-/* The workgroup tile vt_conv2d would run `desc` on, as SPLITK*1000000+BM*1000+BN (-1: invalid descriptor).
+/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS; -1: invalid descriptor).
  * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
 int vt_conv2d_tile(const vt_conv_desc* desc);
 /* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */

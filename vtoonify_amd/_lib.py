@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("out_layout", C.c_int32), ("out_dtype", C.c_int32), ("dtype", C.c_int32),
         ("tile_hint", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("splitk_phase", C.c_int32),
     ]
 
 

@@ -65,6 +65,7 @@ struct ConvArgs {
     int splitk, kps, ldp;
     float* partial;
     int* tickets;       // per-tile arrival counters (zero between launches) or NULL = two-pass split-K
+    int phase;          // 0 = slices + reduce, 1 = slices only, 2 = reduce only (two-pass split-K)
     int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
 };
 
@@ -1035,7 +1036,9 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         return VT_ERR_ARG;
     }
     GldsArgs g;
-    if (glds_eligible<T>(args, g)) {
+    if (args.phase == 2) {
+        // reduce pass only (the slices were launched by an earlier vt_conv2d with phase 1)
+    } else if (glds_eligible<T>(args, g)) {
         // As many LDS stages (K-steps of loads in flight) as still let TWO workgroups share a
         // CU's 160 KiB: measured on MI355X, occupancy 2 with 2 stages beats occupancy 1 with 3
         // (128x128: 2 stages; 128x64 / 64x128: 3; 64x64 and smaller: 4)
@@ -1066,7 +1069,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args);
     }
     int rc = vt_check_launch("vt_conv2d");
-    if (rc != VT_OK || args.splitk == 1 || args.tickets) return rc;
+    if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
     int64_t blocks = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), stream, args);
@@ -1222,10 +1225,12 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         vt_set_error("vt_conv2d: single-buffer patch instance needs one chunk per K slice");
         return VT_ERR_UNSUPPORTED;
     }
-    auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL, NSTB, ABUF>;
-    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+    if (args.phase != 2) {
+        auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL, NSTB, ABUF>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+    }
     int rc = vt_check_launch("vt_conv2d(patch)");
-    if (rc != VT_OK || args.splitk == 1 || args.tickets) return rc;
+    if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
     int64_t rb = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
     if (rb > 4096) rb = 4096;
     VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), stream, args);
@@ -1347,6 +1352,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     const int osz = a.out_f32 ? 4 : 2;
     // workspace layout: [0, VT_TICKET_BYTES) per-tile arrival counters (must be zero when a launch
     // starts; every launch leaves them zero), fp32 slabs after
+    a.phase = d->splitk_phase;
     a.tickets = d->splitk_ws ? (int*)d->splitk_ws : nullptr;
     a.partial = d->splitk_ws ? (float*)((char*)d->splitk_ws + VT_TICKET_BYTES) : nullptr;
     a.vec_store = (d->out_layout == VT_OUT_NHWC) && ((uintptr_t)d->out % 16 == 0) &&
@@ -1371,7 +1377,13 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, wsf);
-    return t.kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
+    int kind = t.kind;
+    if (kind == 0) {  // report which 1-D loader the launch will use: 2 = direct-to-LDS, 0 = register-staged
+        GldsArgs g;
+        const bool glds = d->dtype == VT_BF16 ? glds_eligible<bf16_t>(a, g) : glds_eligible<float>(a, g);
+        kind = glds ? 2 : 0;
+    }
+    return kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
 }
 
 extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {

@@ -148,7 +148,7 @@ class VToonifyEngine:
                   m * cout_t * osz * (2 if d.resid else 1))
         info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
                 "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
-        plan.convs.append((d, info))
+        plan.convs.append((d, info, ops, len(ops)))
         ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
     def _op_linear(self, ops, y, ld_y, x, ld_x, W, b, rows, w_scale=1.0, b_scale=1.0, act=ACT_NONE,
@@ -485,7 +485,7 @@ class VToonifyEngine:
         """One split-K workspace shared by every conv of the plan (launches are serial on one
         stream), then name the kernel instance each descriptor runs on."""
         need = 0
-        for d, _ in plan.convs:
+        for d, _, _, _ in plan.convs:
             b = int(self.lib.vt_conv2d_ws_bytes(C.byref(d)))
             if b < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
@@ -495,16 +495,32 @@ class VToonifyEngine:
             ws = torch.zeros((need,), dtype=torch.uint8, device=self.device)
             plan.bufs["splitk_ws"] = ws
         tname = "bf16" if self.dt == K.VT_BF16 else "f32"
-        for d, info in plan.convs:
+        inserts = []
+        for d, info, ops, pos in plan.convs:
             if ws is not None:
                 d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), need
             tile = self.lib.vt_conv2d_tile(C.byref(d))
             if tile < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
-            kname = "conv_patch" if kind == 1 else "conv_igemm"
-            info["kernel"] = f"{kname}<{tname},{bm}x{bn}>" + (f"+splitk{sk}" if sk > 1 else "")
+            kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel"}[kind]
+            info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
+            if sk > 1:
+                # two-pass split-K as two plan ops (slices, reduce): each is one GPU kernel, so the
+                # per-kernel timings of bench.py line up with rocprofv3's kernel names
+                d.splitk_phase = 1
+                d2 = _lib.ConvDesc.from_buffer_copy(d)
+                d2.splitk_phase = 2
+                plan.keep.append(d2)
+                m, cout_t = info["m"], info["cout"]
+                osz = 4 if d.out_dtype == K.VT_F32 else 2
+                rinfo = {"name": "splitk_reduce", "kernel": "conv_splitk_reduce_kernel", "flops": 0,
+                         "bytes": sk * m * ((cout_t + 7) // 8 * 8) * 4 + m * cout_t * osz}
+                inserts.append((ops, pos, (self.lib.vt_conv2d, (C.byref(d2),), rinfo)))
+        # insert the reduce ops right after their slice ops (back to front keeps positions valid)
+        for ops, pos, op in sorted(inserts, key=lambda t: -t[1]):
+            ops.insert(pos + 1, op)
 
     # ------------------------------------------------------------------ public API
     def _stream(self):
