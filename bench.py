@@ -52,6 +52,32 @@ def state_shapes(backbone: str):
     return {k: tuple(v.shape) for k, v in m.state_dict().items()}
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM bytes per launch of a kernel class from the committed PMC pass
+    (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this
+    same command, corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py).  None when no pass
+    covers the kernel -- counters cannot be collected from inside the timed process."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        table = json.load(f)["kernels"]
+    m = re.match(r"(\w+)<(\w+),(\d+)x(\d+)>", kernel_class)
+    if not m:
+        hit = [v for k, v in table.items() if k.startswith(kernel_class)]
+    else:
+        name, dt, bm, bn = m.group(1), m.group(2), int(m.group(3)), int(m.group(4))
+        tt = "bf16_t" if dt == "bf16" else "float"
+        lead = f"{name}<{tt}, {bm // 16 if name == 'conv_patch_kernel' else bm}, {bn},"
+        hit = [v for k, v in table.items() if k.startswith(lead)]
+    n = sum(v["launches_sampled"] for v in hit)
+    if not n:
+        return None
+    return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hit) / n
+
+
 def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
     """Time the CPU oracle on the host cores.  Sample: ONE frame of the benchmark workload when
     that fits the budget, otherwise a centre crop scaled to it (cost is linear in H*W)."""
@@ -199,7 +225,7 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        roofline["traffic"] = None
+        roofline["traffic"] = pmc_traffic(dom["kernel"])
         roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
                          "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
                          "kernel_sum_ms_per_frame": frame_ms})
