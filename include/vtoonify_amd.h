@@ -40,7 +40,7 @@ enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
 
 /* activation codes of the fused epilogues */
-enum { VT_ACT_NONE = 0, VT_ACT_LRELU = 1, VT_ACT_RELU_TANH = 2 };
+enum { VT_ACT_NONE = 0, VT_ACT_LRELU = 1, VT_ACT_RELU_TANH = 2, VT_ACT_SIGMOID = 3 /* vt_linear only */ };
 /* output layouts of vt_conv2d */
 enum { VT_OUT_NHWC = 0, VT_OUT_NCHW = 1 };
 
@@ -132,6 +132,9 @@ typedef struct vt_conv_desc {
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
                               as separate workgroups and are summed in slice order (deterministic) by a
                               second kernel (or by the last slice to arrive, VT_SPLITK_IN_LAUNCH=1); vt_conv2d_ws_bytes() says how much the heuristic wants */
+    const float* slope_vec; /* optional per-output-channel negative slope [cout] for VT_ACT_LRELU
+                              (nn.PReLU of the pSp encoder, model/encoder/encoders/helpers.py:97-119);
+                              NULL = the scalar `slope` */
     int32_t splitk_phase;  /* two-pass split-K only: 0 = slices + reduce (default), 1 = launch the K
                               slices only, 2 = launch the reduce pass only (lets a caller time or
                               schedule the two kernels separately) */
@@ -219,6 +222,25 @@ int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
  * (NULL = 1, the Toonify backbone, vtoonify.py:262). */
 int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float* mask,
                    const float* skip, int n, int hw, int c, int dtype, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * pSp style-encoder glue (GradualStyleEncoder, model/encoder/encoders/psp_encoders.py:35-116,
+ * bottleneck_IR_SE / SEModule, helpers.py:53-119), NHWC activations.
+ *   vt_channel_mean           AdaptiveAvgPool2d(1): mean[n][c] fp32 (deterministic two-stage
+ *                             reduction; `partials` = vt_instnorm_ws_bytes(n, hw, c) bytes)
+ *   vt_se_apply               out = res * gate[n][c] + shortcut[n, oy*s, ox*s, c]  (s > 1 is the
+ *                             MaxPool2d(1, stride) shortcut, helpers.py:100-101)
+ *   vt_upsample_bilinear_add  F.interpolate(x, (H,W), bilinear, align_corners=True) + y
+ *                             (_upsample_add, psp_encoders.py:71-88)
+ * ReLU / sigmoid of the SE bottleneck run as vt_linear activations (ReLU = VT_ACT_LRELU with
+ * slope 0, gain 1; VT_ACT_SIGMOID).
+ * --------------------------------------------------------------------------------- */
+int vt_channel_mean(float* mean, const void* x, int ld_x, int n, int hw, int c, void* partials,
+                    int dtype, vt_stream stream);
+int vt_se_apply(void* out, const void* res, const float* gate, const void* shortcut, int n, int oh,
+                int ow, int c, int sc_h, int sc_w, int sc_stride, int dtype, vt_stream stream);
+int vt_upsample_bilinear_add(void* out, const void* x, const void* y, int n, int h, int w, int H,
+                             int W, int c, int dtype, vt_stream stream);
 
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,

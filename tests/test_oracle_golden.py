@@ -117,3 +117,17 @@ def test_end_to_end(tag, bb, backend):
     y2 = O.vtoonify_forward(sd, d["x2"], d["style2"], 0.75, bb)
     assert rel_err(y2, d["y2_ds0.75"]) < TOL
     assert rel_err(O.zplus2wplus(sd, d["zplus"], bb), d["wplus"]) < TOL
+
+
+def test_psp_encoder(backend):
+    """oracle/psp_oracle.py vs the reference's GradualStyleEncoder (tests/golden/make_golden_psp.py)."""
+    from oracle import psp_oracle as P
+    d, _ = load_golden("psp.npz")
+    shapes = load_keys("psp")
+    assert len(shapes) == 621
+    sd = synth.to_numpy_sd(synth.synth_state_dict(shapes, 0))
+    for name in ("s32", "s64"):
+        y, (c1, c2, c3, p2, p1) = P.gradual_style_encoder(sd, d[name + "__x"], return_taps=True)
+        assert y.shape == d[name + "__y"].shape
+        assert rel_err(c1, d[name + "__c1"]) < TOL and rel_err(c3, d[name + "__c3"]) < TOL, name
+        assert rel_err(y, d[name + "__y"]) < TOL, name

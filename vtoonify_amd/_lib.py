@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
-ACT_NONE, ACT_LRELU, ACT_RELU_TANH = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_NCHW = 0, 1
 
 
@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("out_layout", C.c_int32), ("out_dtype", C.c_int32), ("dtype", C.c_int32),
         ("tile_hint", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("slope_vec", C.c_void_p),
         ("splitk_phase", C.c_int32),
     ]
 
@@ -90,6 +91,10 @@ _SIGS = {
                                     C.c_void_p]),
     "vt_affine_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vt_channel_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p]),
+    "vt_se_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "vt_upsample_bilinear_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

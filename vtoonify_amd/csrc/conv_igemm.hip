@@ -47,6 +47,7 @@ struct ConvArgs {
     const void* src1;
     const void* wgt;
     const float* bias;
+    const float* slope_vec;
     const float* alpha_dev;
     const float* in_scale;
     const float* in_shift;
@@ -164,9 +165,9 @@ __device__ __forceinline__ void store_nhwc8(const ConvArgs& p, int m, int n, flo
     }
 }
 
-__device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float bias, float ga) {
+__device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float bias, float ga, float slope) {
     v += bias;
-    if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
+    if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * slope;   // slope: scalar or per-channel (PReLU)
     else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
     return v * ga;
 }
@@ -353,12 +354,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
-        float bv[4];
+        float bv[4], sv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nn = n + i;
             const int co = (p.phases > 1) ? nn % p.cout : nn;
             bv[i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
+            sv[i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -366,7 +368,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             if (m < 0 || n >= p.coutT) continue;
             float f[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, acc[a][b][i], bv[i], ga);
+            for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, acc[a][b][i], bv[i], ga, sv[i]);
             store_out4(p, m, n, f);
         }
     }
@@ -961,7 +963,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
             const int nn = n + i;
             const int co = (p.phases > 1) ? nn % p.cout : nn;
             const float bv = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
-            f[i] = conv_finish(p, f[i], bv, ga);
+            f[i] = conv_finish(p, f[i], bv, ga, (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope);
         }
         if (p.out_layout == VT_OUT_NHWC) {
             store_nhwc8(p, m, n, f);
@@ -1315,6 +1317,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.src1 = d->src1;
     a.wgt = d->weight;
     a.bias = d->bias;
+    a.slope_vec = d->slope_vec;
     a.alpha_dev = d->alpha_dev;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;

@@ -300,6 +300,92 @@ nhwc_to_nchw_kernel(TO* __restrict__ out, const TI* __restrict__ in, int ld_in, 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// pSp encoder glue (model/encoder/encoders/helpers.py:53-119, psp_encoders.py:71-88)
+// ---------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(1) from the chunk records of instnorm_partial_kernel: mean[n][c], chunks merged
+// in index order (deterministic).  One thread per (n, c).
+__global__ void __launch_bounds__(256)
+channel_mean_kernel(float* __restrict__ mean, const StatRec* __restrict__ part, int n, int hw, int c,
+                    int chunk_px, int chunks) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * c) return;
+    const int img = idx / c, ch = idx - img * c;
+    double sum = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const StatRec r = part[((int64_t)img * chunks + k) * c + ch];
+        int npx = hw - k * chunk_px;
+        if (npx > chunk_px) npx = chunk_px;
+        sum += (double)r.x0 * npx + (double)r.s1;
+    }
+    mean[idx] = (float)(sum / (double)hw);
+}
+
+// SE gate + residual of bottleneck_IR_SE:  out[n,oy,ox,c] = res[n,oy,ox,c] * gate[n][c]
+//                                                           + sc[n, oy*sc_stride, ox*sc_stride, c]
+// (sc_stride > 1 is MaxPool2d(1, stride) of the block input, helpers.py:100-101).
+template <typename T>
+__global__ void __launch_bounds__(256)
+se_apply_kernel(T* __restrict__ out, const T* __restrict__ res, const float* __restrict__ gate,
+                const T* __restrict__ sc, int n, int oh, int ow, int c, int sc_h, int sc_w, int sc_stride) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cvn = c / VEC;
+    const int64_t total = (int64_t)n * oh * ow * cvn;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % cvn);
+        const int64_t pix = i / cvn;
+        const int ox = (int)(pix % ow);
+        const int64_t t = pix / ow;
+        const int oy = (int)(t % oh), img = (int)(t / oh);
+        float f[VEC], g[VEC];
+        unpack16<T>(ld128(res + pix * c + cv * VEC), f);
+        const int64_t spix = ((int64_t)img * sc_h + (int64_t)oy * sc_stride) * sc_w + (int64_t)ox * sc_stride;
+        unpack16<T>(ld128(sc + spix * c + cv * VEC), g);
+        const float* gt = gate + (int64_t)img * c + cv * VEC;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] = f[k] * gt[k] + g[k];
+        st128(out + pix * c + cv * VEC, pack16<T>(f));
+    }
+}
+
+// F.interpolate(x, size=(H,W), mode='bilinear', align_corners=True) + y   (psp_encoders.py:71-88)
+template <typename T>
+__global__ void __launch_bounds__(256)
+upsample_add_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ y, int n, int h,
+                    int w, int H, int W, int c) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cvn = c / VEC;
+    const int64_t total = (int64_t)n * H * W * cvn;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % cvn);
+        const int64_t pix = i / cvn;
+        const int X = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int Y = (int)(t % H), img = (int)(t / H);
+        const float fy = sy * (float)Y, fx = sx * (float)X;
+        int y0 = (int)fy, x0 = (int)fx;
+        if (y0 > h - 1) y0 = h - 1;
+        if (x0 > w - 1) x0 = w - 1;
+        const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const T* xb = x + (int64_t)img * h * w * c + cv * VEC;
+        float a[VEC], b[VEC], cc[VEC], d[VEC], r[VEC];
+        unpack16<T>(ld128(xb + ((int64_t)y0 * w + x0) * c), a);
+        unpack16<T>(ld128(xb + ((int64_t)y0 * w + x1) * c), b);
+        unpack16<T>(ld128(xb + ((int64_t)y1 * w + x0) * c), cc);
+        unpack16<T>(ld128(xb + ((int64_t)y1 * w + x1) * c), d);
+        unpack16<T>(ld128(y + pix * c + cv * VEC), r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float top = a[k] + (b[k] - a[k]) * lx, bot = cc[k] + (d[k] - cc[k]) * lx;
+            r[k] += top + (bot - top) * ly;
+        }
+        st128(out + pix * c + cv * VEC, pack16<T>(r));
+    }
+}
+
 inline unsigned grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -447,4 +533,66 @@ extern "C" int vt_nhwc_to_nchw(void* out, const void* in, int ld_in, int n, int 
     if (in_dtype == VT_BF16) return nhwc_to_nchw_out<bf16_t>(out, (const bf16_t*)in, ld_in, n, c, hw, out_dtype, stream);
     vt_set_error("vt_nhwc_to_nchw: in dtype");
     return VT_ERR_UNSUPPORTED;
+}
+
+extern "C" int vt_channel_mean(float* mean, const void* x, int ld_x, int n, int hw, int c, void* partials,
+                               int dtype, vt_stream stream) {
+    VT_REQUIRE(mean && x && partials, "vt_channel_mean: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_channel_mean: c must be a positive multiple of 8");
+    VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_channel_mean: dtype");
+    const int cpx = stat_chunk_pixels(hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    dim3 grid((unsigned)(n * chunks)), block(256);
+    if (dtype == VT_F32) {
+        auto k = instnorm_partial_kernel<float, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const float*)x, ld_x, (const float*)nullptr, 0, hw, c, cpx, chunks);
+    } else {
+        auto k = instnorm_partial_kernel<bf16_t, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const bf16_t*)x, ld_x, (const bf16_t*)nullptr, 0, hw, c, cpx, chunks);
+    }
+    int rc = vt_check_launch("vt_channel_mean(partial)");
+    if (rc) return rc;
+    VT_LAUNCH(channel_mean_kernel, dim3((unsigned)((n * c + 255) / 256)), dim3(256), stream, mean,
+              (const StatRec*)partials, n, hw, c, cpx, chunks);
+    return vt_check_launch("vt_channel_mean");
+}
+
+extern "C" int vt_se_apply(void* out, const void* res, const float* gate, const void* shortcut, int n,
+                           int oh, int ow, int c, int sc_h, int sc_w, int sc_stride, int dtype,
+                           vt_stream stream) {
+    VT_REQUIRE(out && res && gate && shortcut, "vt_se_apply: null tensor");
+    VT_REQUIRE(n > 0 && oh > 0 && ow > 0 && c > 0 && c % 8 == 0 && sc_stride >= 1, "vt_se_apply: bad sizes");
+    VT_REQUIRE((oh - 1) * sc_stride < sc_h && (ow - 1) * sc_stride < sc_w, "vt_se_apply: shortcut too small");
+    if (dtype == VT_F32) {
+        auto k = se_apply_kernel<float>;
+        VT_LAUNCH(k, dim3(grid_for((int64_t)n * oh * ow * (c / 4))), dim3(256), stream, (float*)out, (const float*)res,
+                  gate, (const float*)shortcut, n, oh, ow, c, sc_h, sc_w, sc_stride);
+    } else if (dtype == VT_BF16) {
+        auto k = se_apply_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for((int64_t)n * oh * ow * (c / 8))), dim3(256), stream, (bf16_t*)out,
+                  (const bf16_t*)res, gate, (const bf16_t*)shortcut, n, oh, ow, c, sc_h, sc_w, sc_stride);
+    } else {
+        vt_set_error("vt_se_apply: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_se_apply");
+}
+
+extern "C" int vt_upsample_bilinear_add(void* out, const void* x, const void* y, int n, int h, int w, int H,
+                                        int W, int c, int dtype, vt_stream stream) {
+    VT_REQUIRE(out && x && y, "vt_upsample_bilinear_add: null tensor");
+    VT_REQUIRE(n > 0 && h > 0 && w > 0 && H > 0 && W > 0 && c > 0 && c % 8 == 0, "vt_upsample_bilinear_add: bad sizes");
+    if (dtype == VT_F32) {
+        auto k = upsample_add_kernel<float>;
+        VT_LAUNCH(k, dim3(grid_for((int64_t)n * H * W * (c / 4))), dim3(256), stream, (float*)out, (const float*)x,
+                  (const float*)y, n, h, w, H, W, c);
+    } else if (dtype == VT_BF16) {
+        auto k = upsample_add_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(grid_for((int64_t)n * H * W * (c / 8))), dim3(256), stream, (bf16_t*)out, (const bf16_t*)x,
+                  (const bf16_t*)y, n, h, w, H, W, c);
+    } else {
+        vt_set_error("vt_upsample_bilinear_add: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_upsample_bilinear_add");
 }

@@ -36,6 +36,7 @@ linear_kernel(float* __restrict__ y, int ld_y, const float* __restrict__ x, int 
         float v = acc * w_scale;
         if (b) v += b[o] * b_scale;
         if (act == VT_ACT_LRELU) v = ((v > 0.0f) ? v : v * slope) * gain;
+        else if (act == VT_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         y[(int64_t)r * ld_y + o] = v;
     }
 }
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) 
         float v = acc * L.w_scale;
         if (L.b) v += L.b[o] * L.b_scale;
         if (L.act == VT_ACT_LRELU) v = ((v > 0.0f) ? v : v * L.slope) * L.gain;
+        else if (L.act == VT_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         L.y[(int64_t)r * L.ld_y + o] = v;
     }
 }
@@ -292,7 +294,7 @@ extern "C" int vt_linear(float* y, int ld_y, const float* x, int ld_x, const flo
                          float b_scale, int act, float slope, float gain, vt_stream stream) {
     VT_REQUIRE(y && x && W, "vt_linear: null tensor");
     VT_REQUIRE(rows >= 0 && in_dim > 0 && out_dim > 0, "vt_linear: bad sizes");
-    VT_REQUIRE(act == VT_ACT_NONE || act == VT_ACT_LRELU, "vt_linear: unsupported act %d", act);
+    VT_REQUIRE(act == VT_ACT_NONE || act == VT_ACT_LRELU || act == VT_ACT_SIGMOID, "vt_linear: unsupported act %d", act);
     if (rows == 0) return VT_OK;
     const int64_t waves = (int64_t)rows * out_dim;
     VT_LAUNCH(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), stream, y, ld_y, x, ld_x,
@@ -360,7 +362,8 @@ extern "C" int vt_linear_batch(const vt_linear_item* items, int n_items, vt_stre
             const vt_linear_item& L = items[base + i];
             VT_REQUIRE(L.y && L.x && L.W && L.rows > 0 && L.in_dim > 0 && L.out_dim > 0,
                        "vt_linear_batch: item %d: bad tensor/sizes", base + i);
-            VT_REQUIRE(L.act == VT_ACT_NONE || L.act == VT_ACT_LRELU, "vt_linear_batch: unsupported act %d", L.act);
+            VT_REQUIRE(L.act == VT_ACT_NONE || L.act == VT_ACT_LRELU || L.act == VT_ACT_SIGMOID,
+                       "vt_linear_batch: unsupported act %d", L.act);
             t.it[i] = L;
             t.first_wave[i] = (int32_t)waves;
             waves += (int64_t)L.rows * L.out_dim;

@@ -49,6 +49,31 @@ def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
     def randn(scale=1.0):
         return torch.randn(shape, generator=g, dtype=torch.float32) * scale
 
+    # --- pSp GradualStyleEncoder (BatchNorm running stats, PReLU, SE) -------------------
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.int64)
+    if leaf == "running_mean":
+        return randn(0.1)
+    if leaf == "running_var":
+        return torch.rand(shape, generator=g, dtype=torch.float32) + 0.5
+    if leaf in ("weight", "bias") and len(shape) == 1 and (".res_layer." in key or ".shortcut_layer." in key
+                                                             or key.startswith("input_layer.")):
+        # BatchNorm affine (weight ~ 1, bias ~ 0) and PReLU slopes (0.25 at init)
+        is_prelu = key.endswith("res_layer.2.weight") or key == "input_layer.2.weight"
+        if is_prelu:
+            return 0.25 + randn(0.05)
+        return (1.0 + randn(0.1)) if leaf == "weight" else randn(0.1)
+
+    if key.startswith("body.") and leaf == "weight" and len(shape) == 4:
+        # IR-SE-50 convs: half of He init on the residual branch and small SE weights keep the
+        # activations O(10) through 24 residual units (full He init reaches 2e4 and saturates
+        # every SE gate, which makes the net ill-conditioned for a parity test)
+        fan_in = shape[1] * shape[2] * shape[3]
+        if ".res_layer.5." in key:
+            return randn(0.25 * math.sqrt(2.0 / fan_in))
+        if ".res_layer." in key:
+            return randn(0.5 * math.sqrt(2.0 / fan_in))
+
     # --- buffers with fixed semantics -------------------------------------------------
     if key.endswith("blur.kernel"):
         # ModulatedConv2d(upsample=True): Blur(kernel, upsample_factor=2) -> *4
