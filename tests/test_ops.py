@@ -64,6 +64,26 @@ def test_upfirdn2d_dtypes_and_edges(dev, dtype):
             assert rel_err(y.float().cpu().numpy(), ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upfirdn2d_wide_plane_kernel(dev, dtype):
+    """Planes >= 192 output columns with up == down == 1 take the 16x256-tile kernel (4x4 outputs per
+    lane): tile edges, odd widths (unaligned rows -> scalar stores), crops, non-square FIRs."""
+    g = np.random.default_rng(6)
+    k4 = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 16.0).astype(np.float32)
+    k32 = (np.array([[1., 2], [3, 4], [5, 6]]) / 16.0).astype(np.float32)   # asymmetric: catches a missing flip
+    for shape, k, pad in [((2, 3, 35, 513), k4, (1, 1)), ((1, 2, 18, 260), k4, (1, 1)), ((1, 1, 16, 259), k4, (2, 2)),
+                          ((1, 2, 21, 300), k32, (1, 0, 0, 2)), ((1, 1, 40, 270), k4, (-1, 3, 2, -2)),
+                          ((1, 2, 17, 1025), k4, (1, 1))]:
+        x = g.integers(-8, 9, shape).astype(np.float32)
+        y = op.upfirdn2d(T(x, dev, dtype), T(k, dev), pad=pad)
+        ref = O.upfirdn2d(x, k, 1, 1, pad)
+        assert y.shape == ref.shape
+        if dtype == torch.float32:
+            assert np.array_equal(y.cpu().numpy(), ref), (shape, pad)
+        else:
+            assert rel_err(y.float().cpu().numpy(), ref) < 8e-3, (shape, pad)
+
+
 def test_upfirdn2d_properties(dev):
     """Size-independent checks at a realistic size: linearity and the identity kernel."""
     g = torch.Generator().manual_seed(3)

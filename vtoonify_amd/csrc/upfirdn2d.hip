@@ -151,6 +151,120 @@ upfirdn2d_tile(T* __restrict__ out, const T* __restrict__ in, const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide-plane FIR (up == down == 1, the Blur of model/stylegan/model.py:74-90 -- 96 % of the
+// op's bytes in a frame).  HBM-bound: the point is to spend as few instructions per byte as
+// possible.  A 256-thread workgroup produces a 16 x 256 output tile; every lane owns a 4 x 4
+// block of outputs, so one row of its 7 x 7 input footprint is two 16-byte LDS reads
+// (ds_read_b128, lane-consecutive => conflict-free) and each value read is used by up to 16
+// FMAs.  Global loads are issued 5 rows x 5 column passes per lane back to back (all in flight
+// together, 128 contiguous bytes per wavefront pass), stores are 4 consecutive elements per lane
+// (8 B bf16 / 16 B fp32) => a wavefront writes 512 B / 1 KiB contiguous per row.
+// Accumulation order per output is (ky, kx) ascending, as in the other kernels.
+// ---------------------------------------------------------------------------------------
+constexpr int W_TW = 256, W_TH = 16;                 // output tile
+constexpr int W_IH = W_TH + KMAX - 1;                // 19 input rows
+constexpr int W_IW = W_TW + 8;                       // 264 floats per LDS row (259 used; 16-byte rows)
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+upfirdn2d_wide(T* __restrict__ out, const T* __restrict__ in, const float* __restrict__ fir,
+               int in_h, int in_w, int kh, int kw, int pad_x0, int pad_y0, int out_h, int out_w,
+               int tiles_x, int tiles_y, int vec_store) {
+    __shared__ __attribute__((aligned(16))) float s_in[W_IH * W_IW];
+    __shared__ float s_k[KMAX * KMAX];
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, ly = tid >> 6;
+    int64_t b = blockIdx.x;
+    const int tile_x = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int tile_y = (int)(b % tiles_y);
+    const int64_t plane = b / tiles_y;
+    const int oy0 = tile_y * W_TH, ox0 = tile_x * W_TW;
+    const int iy_lo = oy0 - pad_y0, ix_lo = ox0 - pad_x0;   // input coords of window (0,0)
+
+    if (tid < KMAX * KMAX) {
+        const int ky = tid / KMAX, kx = tid % KMAX;
+        s_k[tid] = (ky < kh && kx < kw) ? fir[(kh - 1 - ky) * kw + (kw - 1 - kx)] : 0.0f;
+    }
+    const T* src = in + plane * (int64_t)in_h * in_w;
+    // stage the window: wave `ly` takes rows ly, ly+4, ...; lanes sweep the columns
+    float stg[5][5];
+#pragma unroll
+    for (int rr = 0; rr < 5; ++rr) {
+        const int r = ly + 4 * rr;
+        const int iy = iy_lo + r;
+        const bool rok = r < W_IH && iy >= 0 && iy < in_h;
+        const T* rowp = src + (int64_t)(rok ? iy : 0) * in_w;
+#pragma unroll
+        for (int cp = 0; cp < 5; ++cp) {
+            const int c = lx + 64 * cp;
+            const int ix = ix_lo + c;
+            const bool ok = rok && c < W_IW && ix >= 0 && ix < in_w;
+            stg[rr][cp] = ok ? to_f32(rowp[ix]) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 5; ++rr) {
+        const int r = ly + 4 * rr;
+        if (r < W_IH) {
+#pragma unroll
+            for (int cp = 0; cp < 5; ++cp) {
+                const int c = lx + 64 * cp;
+                if (c < W_IW) s_in[r * W_IW + c] = stg[rr][cp];
+            }
+        }
+    }
+    __syncthreads();
+    float kreg[KMAX * KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX * KMAX; ++i) kreg[i] = s_k[i];
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        float v[8];
+        const float* rowp = s_in + (ly * 4 + r) * W_IW + lx * 4;
+        unpack16<float>(ld128(rowp), v);
+        unpack16<float>(ld128(rowp + 4), v + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ky = r - j;
+            if (ky >= 0 && ky < KMAX) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < KMAX; ++kx) acc[j][i] = fmaf(v[i + kx], kreg[ky * KMAX + kx], acc[j][i]);
+            }
+        }
+    }
+    const int ox = ox0 + lx * 4;
+    T* dst = out + plane * (int64_t)out_h * out_w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + ly * 4 + j;
+        if (oy >= out_h || ox >= out_w) continue;
+        T* o = dst + (int64_t)oy * out_w + ox;
+        if (vec_store && ox + 4 <= out_w) {
+            if (sizeof(T) == 4) {
+                st128(o, pack16<float>(acc[j]));
+            } else {
+                u64v pv;
+                T e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = from_f32<T>(acc[j][i]);
+                memcpy(&pv, e, 8);
+                *reinterpret_cast<u64v*>(o) = pv;
+            }
+        } else {
+            for (int i = 0; i < 4 && ox + i < out_w; ++i) o[i] = from_f32<T>(acc[j][i]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 upfirdn2d_generic(T* __restrict__ out, const T* __restrict__ in, const float* __restrict__ fir,
@@ -189,6 +303,18 @@ int launch_upfirdn2d(void* out, const void* in, const float* fir, int64_t planes
     const bool tileable = up_x == up_y && down_x == down_y && (up_x == 1 || up_x == 2) &&
                           (down_x == 1 || down_x == 2) && !(up_x == 2 && down_x == 2) &&
                           kh <= KMAX && kw <= KMAX;
+    if (tileable && up_x == 1 && down_x == 1 && out_w >= 192) {
+        const int tiles_x = vt_cdiv(out_w, W_TW), tiles_y = vt_cdiv(out_h, W_TH);
+        const int64_t blocks = planes * tiles_x * tiles_y;
+        if (blocks < ((int64_t)1 << 31)) {
+            const int esz = (int)sizeof(T);
+            const int vec = ((uintptr_t)out % (4 * esz) == 0) && (out_w % 4 == 0);
+            auto k = upfirdn2d_wide<T>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (T*)out, (const T*)in, fir, in_h, in_w, kh, kw,
+                      pad_x0, pad_y0, out_h, out_w, tiles_x, tiles_y, vec);
+            return vt_check_launch("upfirdn2d(wide)");
+        }
+    }
     if (tileable) {
         const int tiles_x = vt_cdiv(out_w, TILE_W), tiles_y = vt_cdiv(out_h, TILE_H);
         const int64_t blocks = planes * tiles_x * tiles_y;
