@@ -75,12 +75,25 @@ upfirdn2d_tile(T* __restrict__ out, const T* __restrict__ in, const float* __res
         s_k[tid] = (ky < kh && kx < kw) ? fir[(kh - 1 - ky) * kw + (kw - 1 - kx)] : 0.0f;
     }
     const T* src = in + plane * (int64_t)in_h * in_w;
-    for (int i = tid; i < G::IH * G::IW; i += 256) {
-        const int r = i / G::IW, c = i - r * G::IW;
-        const int iy = iy_lo + r, ix = ix_lo + c;
-        float v = 0.0f;
-        if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = to_f32(src[(int64_t)iy * in_w + ix]);
-        s_in[r * G::LDW + c] = v;
+    {
+        // all of a lane's window loads are issued before the first LDS write (independent loads in
+        // flight together instead of a load -> wait -> ds_write chain per element)
+        constexpr int NLD = (G::IH * G::IW + 255) / 256;
+        float stg[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / G::IW, c = i - r * G::IW;
+            const int iy = iy_lo + r, ix = ix_lo + c;
+            const bool ok = i < G::IH * G::IW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+            stg[j] = ok ? to_f32(src[(int64_t)(ok ? iy : 0) * in_w + (ok ? ix : 0)]) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / G::IW, c = i - r * G::IW;
+            if (i < G::IH * G::IW) s_in[r * G::LDW + c] = stg[j];
+        }
     }
     __syncthreads();
 
