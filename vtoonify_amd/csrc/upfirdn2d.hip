@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256)
 upfirdn2d_wide(T* __restrict__ out, const T* __restrict__ in, const float* __restrict__ fir,
                int in_h, int in_w, int kh, int kw, int pad_x0, int pad_y0, int out_h, int out_w,
                int tiles_x, int tiles_y, int vec_store) {
-    __shared__ __attribute__((aligned(16))) float s_in[W_IH * W_IW];
+    __shared__ __attribute__((aligned(16))) float s_in[20 * W_IW];   // 5 x 4 staged rows (19 used)
     __shared__ float s_k[KMAX * KMAX];
     const int tid = threadIdx.x;
     const int lx = tid & 63, ly = tid >> 6;
@@ -202,31 +202,37 @@ upfirdn2d_wide(T* __restrict__ out, const T* __restrict__ in, const float* __res
     }
     const T* src = in + plane * (int64_t)in_h * in_w;
     // stage the window: wave `ly` takes rows ly, ly+4, ...; lanes sweep the columns
+    // Branch-free: every load is issued unconditionally at a clamped (always legal) address and
+    // masked afterwards -- per-load exec-mask branches cost ~20 scalar instructions each.
     float stg[5][5];
+    int cidx[5];
+    bool cmask[5];
+#pragma unroll
+    for (int cp = 0; cp < 5; ++cp) {
+        const int c = lx + 64 * cp;
+        const int ix = ix_lo + c;
+        cmask[cp] = c < W_IW && ix >= 0 && ix < in_w;
+        cidx[cp] = ix < 0 ? 0 : (ix >= in_w ? in_w - 1 : ix);
+    }
 #pragma unroll
     for (int rr = 0; rr < 5; ++rr) {
         const int r = ly + 4 * rr;
         const int iy = iy_lo + r;
-        const bool rok = r < W_IH && iy >= 0 && iy < in_h;
-        const T* rowp = src + (int64_t)(rok ? iy : 0) * in_w;
+        const bool rmask = r < W_IH && iy >= 0 && iy < in_h;
+        const int iyc = iy < 0 ? 0 : (iy >= in_h ? in_h - 1 : iy);
+        const T* rowp = src + (int64_t)iyc * in_w;
 #pragma unroll
         for (int cp = 0; cp < 5; ++cp) {
-            const int c = lx + 64 * cp;
-            const int ix = ix_lo + c;
-            const bool ok = rok && c < W_IW && ix >= 0 && ix < in_w;
-            stg[rr][cp] = ok ? to_f32(rowp[ix]) : 0.0f;
+            const float v = to_f32(rowp[cidx[cp]]);
+            stg[rr][cp] = (rmask && cmask[cp]) ? v : 0.0f;   // select, not multiply: padding is exactly 0
         }
     }
 #pragma unroll
     for (int rr = 0; rr < 5; ++rr) {
         const int r = ly + 4 * rr;
-        if (r < W_IH) {
 #pragma unroll
-            for (int cp = 0; cp < 5; ++cp) {
-                const int c = lx + 64 * cp;
-                if (c < W_IW) s_in[r * W_IW + c] = stg[rr][cp];
-            }
-        }
+        for (int cp = 0; cp < 4; ++cp) s_in[r * W_IW + lx + 64 * cp] = stg[rr][cp];
+        if (lx < W_IW - 256) s_in[r * W_IW + lx + 256] = stg[rr][4];
     }
     __syncthreads();
     float kreg[KMAX * KMAX];
