@@ -193,6 +193,61 @@ instnorm_finalize_kernel(float* __restrict__ scale, float* __restrict__ shift,
     shift[idx] = beta - gamma * rstd * (float)t.mean;
 }
 
+// finalize + apply in one launch for SMALL tensors (the 32x32-pixel trunk: 12 AdaINs per frame,
+// each 5-6 us of pure launch latency as two kernels).  Every workgroup re-derives scale/shift of
+// all channels from the chunk records (sequential Chan merge in chunk order, fp64 -- a few KB of
+// records, L2 resident) into LDS, then normalises its slice of pixels.
+template <typename T>
+__global__ void __launch_bounds__(256)
+instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
+                            const StatRec* __restrict__ part, int hw, int c, int chunk_px, int chunks,
+                            const float* __restrict__ style_gb, int ld_gb, int px_per_block) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float s_aff[2 * 2048];   // [2][c], c <= 2048
+    const int blocks_per_img = (hw + px_per_block - 1) / px_per_block;
+    const int img = blockIdx.x / blocks_per_img;
+    const int p0 = (blockIdx.x - img * blocks_per_img) * px_per_block;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        double cnt = 0.0, mean = 0.0, m2 = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const StatRec r = part[((int64_t)img * chunks + k) * c + ch];
+            int npx = hw - k * chunk_px;
+            if (npx > chunk_px) npx = chunk_px;
+            const double nb = (double)npx;
+            const double mb = (double)r.x0 + (double)r.s1 / nb;
+            const double m2b = (double)r.s2 - (double)r.s1 * (double)r.s1 / nb;
+            const double delta = mb - mean;
+            const double tot = cnt + nb;
+            mean += delta * nb / tot;
+            m2 += m2b + delta * delta * cnt * nb / tot;
+            cnt = tot;
+        }
+        double var = m2 / cnt;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
+        float gamma = 1.0f, beta = 0.0f;
+        if (style_gb) {
+            gamma = style_gb[(int64_t)img * ld_gb + ch];
+            beta = style_gb[(int64_t)img * ld_gb + c + ch];
+        }
+        s_aff[ch] = gamma * rstd;
+        s_aff[c + ch] = beta - gamma * rstd * (float)mean;
+    }
+    __syncthreads();
+    const int cvn = c / VEC;
+    const int p1 = (p0 + px_per_block < hw) ? p0 + px_per_block : hw;
+    const int total = (p1 - p0) * cvn;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int cv = i % cvn;
+        const int64_t pix = (int64_t)img * hw + p0 + i / cvn;
+        float f[VEC];
+        unpack16<T>(ld128(x + pix * ld_x + cv * VEC), f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] = f[k] * s_aff[cv * VEC + k] + s_aff[c + cv * VEC + k];
+        st128(out + pix * ld_out + cv * VEC, pack16<T>(f));
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 affine_apply_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
@@ -595,4 +650,43 @@ extern "C" int vt_upsample_bilinear_add(void* out, const void* x, const void* y,
         return VT_ERR_UNSUPPORTED;
     }
     return vt_check_launch("vt_upsample_bilinear_add");
+}
+
+// AdaIN in two launches (statistics + fused finalize/apply) when the tensor is small enough for
+// every workgroup to re-derive all channel statistics; returns VT_ERR_UNSUPPORTED otherwise (use
+// vt_instnorm_stats + vt_affine_apply).
+extern "C" int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
+                                 const float* style_gb, int ld_gb, void* partials, int dtype,
+                                 vt_stream stream) {
+    VT_REQUIRE(out && x && partials, "vt_instnorm_apply: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 16 == 0, "vt_instnorm_apply: c must be a positive multiple of 16");
+    VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_apply: dtype");
+    const int cpx = stat_chunk_pixels(hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    if ((int64_t)chunks * c * 12 > (1 << 20) || c > 2048) {
+        vt_set_error("vt_instnorm_apply: tensor too large for the fused form");
+        return VT_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)(n * chunks)), block(256);
+    if (dtype == VT_F32) {
+        auto k = instnorm_partial_kernel<float, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const float*)x, ld_x, (const float*)nullptr, 0, hw, c, cpx, chunks);
+    } else {
+        auto k = instnorm_partial_kernel<bf16_t, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const bf16_t*)x, ld_x, (const bf16_t*)nullptr, 0, hw, c, cpx, chunks);
+    }
+    int rc = vt_check_launch("vt_instnorm_apply(partial)");
+    if (rc) return rc;
+    const int ppb = 16;
+    const unsigned nblk = (unsigned)(n * ((hw + ppb - 1) / ppb));
+    if (dtype == VT_F32) {
+        auto k = instnorm_apply_small_kernel<float>;
+        VT_LAUNCH(k, dim3(nblk), block, stream, (float*)out, ld_out, (const float*)x, ld_x,
+                      (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb, ppb);
+    } else {
+        auto k = instnorm_apply_small_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(nblk), block, stream, (bf16_t*)out, ld_out, (const bf16_t*)x, ld_x,
+                      (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb, ppb);
+    }
+    return vt_check_launch("vt_instnorm_apply");
 }

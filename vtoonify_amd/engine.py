@@ -353,21 +353,30 @@ class VToonifyEngine:
                 # AdaResBlock (dualstylegan.py:38-45): AdaIN folded into the conv loader
                 for nm, src, dst in (("norm", feat, tmp), ("norm2", tmp, None)):
                     gb = plan.bufs[f"gb.res.{r}.{nm}"]
-                    ops.append((lib.vt_instnorm_stats,
-                                (C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()), C.c_void_p(src.data_ptr()),
-                                 cf, C.c_void_p(0), 0, B, hw, cf, C.c_void_p(gb.data_ptr()),
-                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
-                                {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
-                                 "bytes": B * hw * cf * self.esz}))
-                    # AdaIN applied as its own streaming pass (1 MB at 32x32x512) so that the conv
-                    # runs the direct-to-LDS loader; the fused in-loader affine (in_scale/in_shift
-                    # of vt_conv2d) costs more in the MFMA loop than this pass does
-                    ops.append((lib.vt_affine_apply,
-                                (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf,
-                                 C.c_void_p(0), 0, C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()),
-                                 B, hw, cf, dt),
-                                {"name": "affine", "kernel": "affine_apply", "flops": 0,
-                                 "bytes": 2 * B * hw * cf * self.esz}))
+                    # AdaIN as statistics + one fused finalize/apply launch (small tensor), written to
+                    # its own buffer so that the conv runs the direct-to-LDS loader; the in-loader
+                    # affine (in_scale/in_shift of vt_conv2d) costs more in the MFMA loop than this
+                    cpx = max(16, min(4096, (hw + 255) // 256))       # stat_chunk_pixels (norm_glue.hip)
+                    if ((hw + cpx - 1) // cpx) * cf * 12 <= (1 << 20) and cf <= 2048:
+                        ops.append((lib.vt_instnorm_apply,
+                                    (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
+                                     C.c_void_p(gb.data_ptr()), 0 if ns == 1 else gb.shape[1],
+                                     C.c_void_p(ws.data_ptr()), dt),
+                                    {"name": "adain", "kernel": "instnorm_apply", "flops": 0,
+                                     "bytes": 3 * B * hw * cf * self.esz}))
+                    else:   # large planes: separate finalize (parallel tree merge) and apply
+                        ops.append((lib.vt_instnorm_stats,
+                                    (C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()), C.c_void_p(src.data_ptr()),
+                                     cf, C.c_void_p(0), 0, B, hw, cf, C.c_void_p(gb.data_ptr()),
+                                     0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
+                                    {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
+                                     "bytes": B * hw * cf * self.esz}))
+                        ops.append((lib.vt_affine_apply,
+                                    (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf,
+                                     C.c_void_p(0), 0, C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()),
+                                     B, hw, cf, dt),
+                                    {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                     "bytes": 2 * B * hw * cf * self.esz}))
                     cn = "conv" if nm == "norm" else "conv2"
                     if dst is not None:
                         self._op_conv(ops, plan, src0=nrm_res, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
