@@ -208,20 +208,27 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
     const int img = blockIdx.x / blocks_per_img;
     const int p0 = (blockIdx.x - img * blocks_per_img) * px_per_block;
     for (int ch = threadIdx.x; ch < c; ch += 256) {
-        double cnt = 0.0, mean = 0.0, m2 = 0.0;
+        // division-free merge (fp64 divides cost ~100 cycles each and made this kernel 50 us):
+        //   mean = sum_k (x0_k n_k + s1_k) / hw
+        //   M2   = sum_k [ s2_k - 2 d_k s1_k + n_k d_k^2 ],  d_k = mean - x0_k   (exact algebra)
+        const StatRec* pc = part + (int64_t)img * chunks * c + ch;
+        double sum = 0.0;
         for (int k = 0; k < chunks; ++k) {
-            const StatRec r = part[((int64_t)img * chunks + k) * c + ch];
+            const StatRec r = pc[(int64_t)k * c];
             int npx = hw - k * chunk_px;
             if (npx > chunk_px) npx = chunk_px;
-            const double nb = (double)npx;
-            const double mb = (double)r.x0 + (double)r.s1 / nb;
-            const double m2b = (double)r.s2 - (double)r.s1 * (double)r.s1 / nb;
-            const double delta = mb - mean;
-            const double tot = cnt + nb;
-            mean += delta * nb / tot;
-            m2 += m2b + delta * delta * cnt * nb / tot;
-            cnt = tot;
+            sum += (double)r.x0 * (double)npx + (double)r.s1;
         }
+        const double mean = sum / (double)hw;
+        double m2 = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const StatRec r = pc[(int64_t)k * c];
+            int npx = hw - k * chunk_px;
+            if (npx > chunk_px) npx = chunk_px;
+            const double d = mean - (double)r.x0;
+            m2 += (double)r.s2 - 2.0 * d * (double)r.s1 + (double)npx * d * d;
+        }
+        const double cnt = (double)hw;
         double var = m2 / cnt;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
