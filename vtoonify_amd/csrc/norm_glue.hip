@@ -211,22 +211,38 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
         // division-free merge (fp64 divides cost ~100 cycles each and made this kernel 50 us):
         //   mean = sum_k (x0_k n_k + s1_k) / hw
         //   M2   = sum_k [ s2_k - 2 d_k s1_k + n_k d_k^2 ],  d_k = mean - x0_k   (exact algebra)
+        // Records are fetched 8 at a time (independent loads in flight; a one-load-per-iteration
+        // loop is a chain of L2 round trips) and folded in chunk order.
         const StatRec* pc = part + (int64_t)img * chunks * c + ch;
         double sum = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            const StatRec r = pc[(int64_t)k * c];
-            int npx = hw - k * chunk_px;
-            if (npx > chunk_px) npx = chunk_px;
-            sum += (double)r.x0 * (double)npx + (double)r.s1;
+        for (int k0 = 0; k0 < chunks; k0 += 8) {
+            StatRec r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = pc[(int64_t)((k0 + u < chunks) ? k0 + u : k0) * c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k >= chunks) break;
+                int npx = hw - k * chunk_px;
+                if (npx > chunk_px) npx = chunk_px;
+                sum += (double)r[u].x0 * (double)npx + (double)r[u].s1;
+            }
         }
         const double mean = sum / (double)hw;
         double m2 = 0.0;
-        for (int k = 0; k < chunks; ++k) {
-            const StatRec r = pc[(int64_t)k * c];
-            int npx = hw - k * chunk_px;
-            if (npx > chunk_px) npx = chunk_px;
-            const double d = mean - (double)r.x0;
-            m2 += (double)r.s2 - 2.0 * d * (double)r.s1 + (double)npx * d * d;
+        for (int k0 = 0; k0 < chunks; k0 += 8) {
+            StatRec r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = pc[(int64_t)((k0 + u < chunks) ? k0 + u : k0) * c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k >= chunks) break;
+                int npx = hw - k * chunk_px;
+                if (npx > chunk_px) npx = chunk_px;
+                const double d = mean - (double)r[u].x0;
+                m2 += (double)r[u].s2 - 2.0 * d * (double)r[u].s1 + (double)npx * d * d;
+            }
         }
         const double cnt = (double)hw;
         double var = m2 / cnt;
