@@ -212,9 +212,9 @@ int vt_instnorm_stats(float* scale, float* shift, const void* x, int ld_x,
                       const void* absdiff_other, int ld_other, int n, int hw, int c,
                       const float* style_gb, int ld_gb, void* partials, int dtype,
                       vt_stream stream);
-/* AdaIN(x) in two launches for SMALL tensors (chunk records <= 1 MiB, c <= 2048 -- the 32x32-pixel
- * trunk): statistics, then one kernel that derives scale/shift of every channel in each workgroup
- * and applies them.  VT_ERR_UNSUPPORTED for larger tensors (use vt_instnorm_stats +
+/* AdaIN(x) in two launches for SMALL planes (hw <= 16384 -- the 32x32-pixel trunk): statistics,
+ * then one kernel whose workgroups each own one 16-byte channel vector: fold its chunk records,
+ * normalise every pixel of the plane.  VT_ERR_UNSUPPORTED for larger tensors (use vt_instnorm_stats +
  * vt_affine_apply). */
 int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
                       const float* style_gb, int ld_gb, void* partials, int dtype, vt_stream stream);

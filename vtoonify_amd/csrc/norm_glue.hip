@@ -194,58 +194,55 @@ instnorm_finalize_kernel(float* __restrict__ scale, float* __restrict__ shift,
 }
 
 // finalize + apply in one launch for SMALL tensors (the 32x32-pixel trunk: 12 AdaINs per frame,
-// each 5-6 us of pure launch latency as two kernels).  Every workgroup re-derives scale/shift of
-// all channels from the chunk records (sequential Chan merge in chunk order, fp64 -- a few KB of
-// records, L2 resident) into LDS, then normalises its slice of pixels.
+// each 5-6 us of pure launch latency as two kernels).  One workgroup per (image, 16-byte channel
+// vector): it folds the chunk records of ITS channels only (a few KB -- letting every workgroup
+// re-derive all channels made the kernel L2-bound at 30-50 us), then walks all pixels of the plane.
+// Merge (fp64, fixed order, no divisions in the loop):
+//   mean = sum_k (x0_k n_k + s1_k) / hw ;  M2 = sum_k [ s2_k - 2 d_k s1_k + n_k d_k^2 ], d_k = mean - x0_k
 template <typename T>
 __global__ void __launch_bounds__(256)
 instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
                             const StatRec* __restrict__ part, int hw, int c, int chunk_px, int chunks,
-                            const float* __restrict__ style_gb, int ld_gb, int px_per_block) {
+                            const float* __restrict__ style_gb, int ld_gb) {
     constexpr int VEC = 16 / sizeof(T);
-    __shared__ float s_aff[2 * 2048];   // [2][c], c <= 2048
-    const int blocks_per_img = (hw + px_per_block - 1) / px_per_block;
-    const int img = blockIdx.x / blocks_per_img;
-    const int p0 = (blockIdx.x - img * blocks_per_img) * px_per_block;
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
-        // division-free merge (fp64 divides cost ~100 cycles each and made this kernel 50 us):
-        //   mean = sum_k (x0_k n_k + s1_k) / hw
-        //   M2   = sum_k [ s2_k - 2 d_k s1_k + n_k d_k^2 ],  d_k = mean - x0_k   (exact algebra)
-        // Records are fetched 8 at a time (independent loads in flight; a one-load-per-iteration
-        // loop is a chain of L2 round trips) and folded in chunk order.
-        const StatRec* pc = part + (int64_t)img * chunks * c + ch;
-        double sum = 0.0;
-        for (int k0 = 0; k0 < chunks; k0 += 8) {
-            StatRec r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = pc[(int64_t)((k0 + u < chunks) ? k0 + u : k0) * c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u;
-                if (k >= chunks) break;
-                int npx = hw - k * chunk_px;
-                if (npx > chunk_px) npx = chunk_px;
-                sum += (double)r[u].x0 * (double)npx + (double)r[u].s1;
-            }
-        }
-        const double mean = sum / (double)hw;
-        double m2 = 0.0;
-        for (int k0 = 0; k0 < chunks; k0 += 8) {
-            StatRec r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = pc[(int64_t)((k0 + u < chunks) ? k0 + u : k0) * c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u;
-                if (k >= chunks) break;
-                int npx = hw - k * chunk_px;
-                if (npx > chunk_px) npx = chunk_px;
-                const double d = mean - (double)r[u].x0;
-                m2 += (double)r[u].s2 - 2.0 * d * (double)r[u].s1 + (double)npx * d * d;
-            }
-        }
-        const double cnt = (double)hw;
-        double var = m2 / cnt;
+    constexpr int PARTS = 256 / VEC;          // threads cooperating per channel
+    __shared__ double s_red[256];
+    __shared__ float s_aff[2 * VEC];
+    const int cvn = c / VEC;
+    const int img = blockIdx.x / cvn, cv = blockIdx.x - img * cvn;
+    const int tid = threadIdx.x;
+    const int chl = tid % VEC, pt = tid / VEC;
+    const int ch = cv * VEC + chl;
+    const StatRec* pc = part + (int64_t)img * chunks * c + ch;
+    // pass 1: mean
+    double sum = 0.0;
+    for (int k = pt; k < chunks; k += PARTS) {
+        const StatRec r = pc[(int64_t)k * c];
+        int npx = hw - k * chunk_px;
+        if (npx > chunk_px) npx = chunk_px;
+        sum += (double)r.x0 * (double)npx + (double)r.s1;
+    }
+    s_red[tid] = sum;
+    __syncthreads();
+    double tot = 0.0;
+    for (int j = 0; j < PARTS; ++j) tot += s_red[j * VEC + chl];   // same fixed order in every thread
+    const double mean = tot / (double)hw;
+    __syncthreads();
+    // pass 2: M2 around that mean
+    double m2 = 0.0;
+    for (int k = pt; k < chunks; k += PARTS) {
+        const StatRec r = pc[(int64_t)k * c];
+        int npx = hw - k * chunk_px;
+        if (npx > chunk_px) npx = chunk_px;
+        const double d = mean - (double)r.x0;
+        m2 += (double)r.s2 - 2.0 * d * (double)r.s1 + (double)npx * d * d;
+    }
+    s_red[tid] = m2;
+    __syncthreads();
+    if (pt == 0) {
+        double t2 = 0.0;
+        for (int j = 0; j < PARTS; ++j) t2 += s_red[j * VEC + chl];
+        double var = t2 / (double)hw;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)IN_EPS));
         float gamma = 1.0f, beta = 0.0f;
@@ -253,20 +250,22 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
             gamma = style_gb[(int64_t)img * ld_gb + ch];
             beta = style_gb[(int64_t)img * ld_gb + c + ch];
         }
-        s_aff[ch] = gamma * rstd;
-        s_aff[c + ch] = beta - gamma * rstd * (float)mean;
+        s_aff[chl] = gamma * rstd;
+        s_aff[VEC + chl] = beta - gamma * rstd * (float)mean;
     }
     __syncthreads();
-    const int cvn = c / VEC;
-    const int p1 = (p0 + px_per_block < hw) ? p0 + px_per_block : hw;
-    const int total = (p1 - p0) * cvn;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int cv = i % cvn;
-        const int64_t pix = (int64_t)img * hw + p0 + i / cvn;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        sc[k] = s_aff[k];
+        sh[k] = s_aff[VEC + k];
+    }
+    for (int p = tid; p < hw; p += 256) {
+        const int64_t pix = (int64_t)img * hw + p;
         float f[VEC];
         unpack16<T>(ld128(x + pix * ld_x + cv * VEC), f);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) f[k] = f[k] * s_aff[cv * VEC + k] + s_aff[c + cv * VEC + k];
+        for (int k = 0; k < VEC; ++k) f[k] = f[k] * sc[k] + sh[k];
         st128(out + pix * ld_out + cv * VEC, pack16<T>(f));
     }
 }
@@ -686,7 +685,7 @@ extern "C" int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x,
     VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_apply: dtype");
     const int cpx = stat_chunk_pixels(hw);
     const int chunks = (hw + cpx - 1) / cpx;
-    if ((int64_t)chunks * c * 12 > (1 << 20) || c > 2048) {
+    if ((int64_t)hw > 16384) {   // one workgroup walks a whole plane: small planes only
         vt_set_error("vt_instnorm_apply: tensor too large for the fused form");
         return VT_ERR_UNSUPPORTED;
     }
@@ -700,16 +699,15 @@ extern "C" int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x,
     }
     int rc = vt_check_launch("vt_instnorm_apply(partial)");
     if (rc) return rc;
-    const int ppb = 16;
-    const unsigned nblk = (unsigned)(n * ((hw + ppb - 1) / ppb));
+    const unsigned nblk = (unsigned)(n * (c / (dtype == VT_F32 ? 4 : 8)));
     if (dtype == VT_F32) {
         auto k = instnorm_apply_small_kernel<float>;
         VT_LAUNCH(k, dim3(nblk), block, stream, (float*)out, ld_out, (const float*)x, ld_x,
-                      (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb, ppb);
+                  (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb);
     } else {
         auto k = instnorm_apply_small_kernel<bf16_t>;
         VT_LAUNCH(k, dim3(nblk), block, stream, (bf16_t*)out, ld_out, (const bf16_t*)x, ld_x,
-                      (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb, ppb);
+                  (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb);
     }
     return vt_check_launch("vt_instnorm_apply");
 }

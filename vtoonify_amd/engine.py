@@ -356,8 +356,7 @@ class VToonifyEngine:
                     # AdaIN as statistics + one fused finalize/apply launch (small tensor), written to
                     # its own buffer so that the conv runs the direct-to-LDS loader; the in-loader
                     # affine (in_scale/in_shift of vt_conv2d) costs more in the MFMA loop than this
-                    cpx = max(16, min(4096, (hw + 255) // 256))       # stat_chunk_pixels (norm_glue.hip)
-                    if ((hw + cpx - 1) // cpx) * cf * 12 <= (1 << 20) and cf <= 2048:
+                    if hw <= 16384:   # vt_instnorm_apply: fused finalize+apply for small planes
                         ops.append((lib.vt_instnorm_apply,
                                     (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
                                      C.c_void_p(gb.data_ptr()), 0 if ns == 1 else gb.shape[1],
