@@ -174,17 +174,17 @@ def main():
     torch.cuda.synchronize()
     assert tuple(y.shape) == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(y).all())
 
-    if ws > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if ws > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if ws > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +267,7 @@ def main():
         result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result))
-    if ws > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

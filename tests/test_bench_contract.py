@@ -1,0 +1,51 @@
+"""bench.py contract: argument surface on CPU, and on the GPU box the real thing -- a short N=1 run
+and the same command under torch.distributed.run with one rank (RCCL init + weight/style broadcast
+path of vtoonify_amd/frames.py; multi-GPU boxes are the driver's, the code path is identical)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_to_run_without_gpu_or_with_wrong_world_size():
+    env = dict(os.environ, WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _check(line):
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert d["value"] > 30.0, "north-star floor: >= 30 frames/s at 1024x1024 on one MI355X"
+    return d
+
+
+@pytest.mark.gpu
+def test_bench_single_process():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--op-iters", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["cpu_baseline"] is None or d["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_one_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--op-iters", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])

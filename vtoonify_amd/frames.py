@@ -34,7 +34,9 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed when WORLD_SIZE > 1.  backend: "nccl" (= RCCL) on GPU
     ranks, "gloo" for CPU tests; default picks by device availability."""
     rank, local_rank, ws = world()
-    if ws > 1 and not dist.is_initialized():
+    # under a launcher (RANK set) the group is created even for one rank, so that the RCCL
+    # broadcast path is the one exercised on a single-GPU box too
+    if (ws > 1 or "RANK" in os.environ) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
