@@ -93,7 +93,7 @@ def broadcast_state_dict(shapes: Dict[str, Tuple[int, ...]], sd: Optional[Dict[s
                 m = _numel(shapes[k])
                 flat[off:off + m].copy_(sd[k].reshape(-1).to(torch.float32))
                 off += m
-        if ws > 1:
+        if dist.is_initialized():
             dist.broadcast(flat, src=src)
         off = 0
         for k in keys[i:j]:
@@ -112,7 +112,7 @@ def broadcast_style(style: Optional[torch.Tensor], d_s: Optional[float], device:
     if rank == src:
         buf[:-1].copy_(style.reshape(-1).to(torch.float32))
         buf[-1] = float(d_s)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.broadcast(buf, src=src)
     return buf[:-1].view(1, 18, 512).clone(), float(buf[-1].item())
 
