@@ -268,7 +268,7 @@ def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
                       expect_kind=1) < t                                                               # mask conv
     # every compiled patch tile, forced by hint (S=0: auto split; S=2 forced)
     for hint in (P + 256128, P + 256064, P + 128064, P + 128016, P + 2000000 + 128064, P + 2000000 + 256128,
-                 P + 128128, P + 1000000 + 128128, P + 2000000 + 128128, P + 128032, P + 2000000 + 128032):
+                 P + 128128, P + 1000000 + 128128, P + 2000000 + 128128):
         assert _conv_case(dev, dtype, 1, 128, 21, 35, 136, 3, 1, 1, 1, act=L, hint=hint, resid=True, ws=True,
                           seed=hint % 97) < t, hint
     # 1-D direct-to-LDS kernels (patch disabled with P=2), incl. stride 2 and a 1x1 conv, with split-K

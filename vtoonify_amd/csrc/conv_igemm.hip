@@ -1266,11 +1266,6 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         VT_PATCH(8, 128, 2, 2, 2, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 4, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 1, 6, 2, !one_chunk)
-        // 32x32-pixel trunk: narrow N tiles fill the chip with only 2 K slices (4x less split-K
-        // traffic than 128-wide tiles need), 8-deep weight ring
-        VT_PATCH(8, 32, 4, 1, 1, 8, 2, true)
-        VT_PATCH(8, 32, 4, 1, 2, 8, 2, true)
-        VT_PATCH(8, 32, 4, 1, 4, 8, 2, true)
 #undef VT_PATCH
         vt_set_error("vt_conv2d: no compiled patch tile %dx%d dil %d", t.bm, t.bn, a.dil);
         return VT_ERR_UNSUPPORTED;
