@@ -76,8 +76,6 @@ class VToonifyEngine:
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
-        self.overlap = True          # two-stream issue (style path || encoder, skip chain || convs)
-        self._side = None
         self._style_key = None
         self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.g = "generator.generator." if self.dual else "generator."
@@ -133,7 +131,7 @@ class VToonifyEngine:
         plan.bufs[name] = t
         return t
 
-    def _op_conv(self, ops, plan, ref_macs=None, lane="main", **kw):
+    def _op_conv(self, ops, plan, ref_macs=None, **kw):
         """Append one vt_conv2d launch.  The op's info records the kernel instance (tile) and
         its ALGORITHMIC work: flops = 2 x the MACs of the reference contraction it replaces
         (`ref_macs` overrides that for the fused conv_transpose2d+blur form, whose polyphase
@@ -149,7 +147,7 @@ class VToonifyEngine:
         nbytes = (d.n * d.h * d.w * cin * self.esz + cout_t * d.kh * d.kw * cin * self.esz +
                   m * cout_t * osz * (2 if d.resid else 1))
         info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
-                "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w), "lane": lane}
+                "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
         plan.convs.append((d, info, ops, len(ops)))
         ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
@@ -167,34 +165,12 @@ class VToonifyEngine:
             return what
         return {"name": what, "kernel": what, "flops": 0, "bytes": 0}
 
-    def _run(self, ops, stream, side=None):
-        """Issue ops in list order.  Ops whose info carries lane == "side" go to the side stream
-        (when one is given): short, narrow kernels -- fusion_skip convs, the RGB-skip FIR upsample --
-        that are independent of the chip-filling convs issued next on the main stream.  "fork" /
-        "join" marker ops order the two streams with events (captured as graph edges under hipGraph
-        capture).  side=None runs everything in order on `stream` (per-kernel timing, emulation)."""
+    def _run(self, ops, stream):
         for fn, args, what in ops:
-            info = self._info(what)
-            if fn is None:
-                if side is not None:
-                    ev = torch.cuda.Event()
-                    if info["name"] == "fork":
-                        ev.record(torch.cuda.current_stream(self.device))
-                        side.wait_event(ev)
-                    else:
-                        ev.record(side)
-                        torch.cuda.current_stream(self.device).wait_event(ev)
-                continue
-            st = stream
-            if side is not None and info.get("lane") == "side":
-                st = C.c_void_p(side.cuda_stream)
-            rc = fn(*args, st)
+            rc = fn(*args, stream)
             if rc != 0:
-                raise _lib.VtError(f"{info['name']} failed (code {rc}): {self.lib.vt_last_error().decode()}")
-
-    @staticmethod
-    def _marker(name):
-        return (None, (), {"name": name, "kernel": name, "flops": 0, "bytes": 0})
+                raise _lib.VtError(f"{self._info(what)['name']} failed (code {rc}): "
+                                   f"{self.lib.vt_last_error().decode()}")
 
     # ------------------------------------------------------------------ style path
     def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
@@ -361,7 +337,6 @@ class VToonifyEngine:
         feat = cur
         pp = 0
         rk = f"encoder.{self.n_down}"
-        plan.enc_split = len(ops)   # ops before this index do not read style-path outputs
         for ii in range(6):
             self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                           weight=self.w[f"{rk}.{ii}.conv"], cout=cf, kh=3, kw=3, pad=1,
@@ -428,7 +403,6 @@ class VToonifyEngine:
         out, co = feat, cf
         for lvl in range(5):
             hw = h * w
-            forked = False
             if lvl < self.n_fuse:
                 f_e, ce, he, we = feats[lvl]
                 assert (he, we) == (h, w) and ce == co, "encoder/generator size mismatch (H, W must be multiples of 8)"
@@ -465,15 +439,13 @@ class VToonifyEngine:
                              B, hw, co, dt),
                             {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0,
                              "bytes": B * hw * (co * self.esz + (co + 8) * self.esz + 16)}))
-                ops.append(self._marker("fork"))
-                forked = True
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
                 self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + 8 * self.esz, c1=co,
                               ld1=co + 8, n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[wkey], cout=co, kh=3,
                               kw=3, pad=1, bias=sd[wkey + ".bias"], out=fo, ld_out=co)
                 sk2 = self._buf(plan, f"fskip{lvl}", (B, 3, h, w), f32)
-                self._op_conv(ops, plan, lane="side", src0=fem, c0=co + 8, ld0=co + 8, n=B, h=h, w=w, out_h=h, out_w=w,
+                self._op_conv(ops, plan, src0=fem, c0=co + 8, ld0=co + 8, n=B, h=h, w=w, out_h=h, out_w=w,
                               weight=self.w[f"fusion_skip.{lvl}"], cout=3, kh=3, kw=3, pad=1,
                               bias=sd[f"fusion_skip.{lvl}.bias"], out=sk2, ld_out=0, out_layout=OUT_NCHW,
                               out_dtype=K.VT_F32)
@@ -483,15 +455,12 @@ class VToonifyEngine:
             up = self._buf(plan, f"up{lvl}", (B, 2 * h, 2 * w, c1o))
             o2 = self._buf(plan, f"gout{lvl}", (B, 2 * h, 2 * w, c1o))
             rgb = self._buf(plan, f"rgb{lvl}", (B, 3, 2 * h, 2 * w), f32)
-            if not forked:
-                ops.append(self._marker("fork"))
-            # skip = Upsample(skip): upfirdn2d up=2 pad=(2,1) (model.py:32-50), fp32 planes -- on the
-            # side stream together with the fusion_skip conv that feeds it
+            # skip = Upsample(skip): upfirdn2d up=2 pad=(2,1) (model.py:32-50), fp32 planes
             ops.append((lib.vt_upfirdn2d,
                         (C.c_void_p(rgb.data_ptr()), C.c_void_p(skip.data_ptr()), C.c_void_p(self.fir_rgb.data_ptr()),
                          B * 3, h, w, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, K.VT_F32),
                         {"name": "upfirdn2d", "kernel": "upfirdn2d_tile<f32,up2>", "flops": 0,
-                         "bytes": B * 3 * hw * 5 * 4, "lane": "side"}))
+                         "bytes": B * 3 * hw * 5 * 4}))
             groups = [(0, B)] if ns == 1 else [(b, 1) for b in range(B)]
             for b0, nb in groups:
                 sidx = 0 if ns == 1 else b0
@@ -509,8 +478,6 @@ class VToonifyEngine:
                               h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm2, cout=c1o, kh=3, kw=3, pad=1,
                               bias=sd[f"{g}{n2}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
                               out=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
-                if (b0, nb) == groups[0]:
-                    ops.append(self._marker("join"))   # the up-sampled skip must be there
                 # ToRGB: 1x1 modulated conv (no demod) + bias + up-sampled skip (model.py:383-392)
                 self._op_conv(ops, plan, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
                               h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
@@ -525,23 +492,21 @@ class VToonifyEngine:
     def _finalize_convs(self, plan: _Plan):
         """One split-K workspace shared by every conv of the plan (launches are serial on one
         stream), then name the kernel instance each descriptor runs on."""
-        need = {"main": 0, "side": 0}
-        for d, info, _, _ in plan.convs:
+        need = 0
+        for d, _, _, _ in plan.convs:
             b = int(self.lib.vt_conv2d_ws_bytes(C.byref(d)))
             if b < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
-            need[info["lane"]] = max(need[info["lane"]], b)
-        wsl = {}
-        for lane, nb in need.items():   # one workspace per stream: launches on a stream are serial
-            if nb:  # zero-filled: the head of the workspace holds the split-K arrival counters
-                wsl[lane] = torch.zeros((nb,), dtype=torch.uint8, device=self.device)
-                plan.bufs["splitk_ws_" + lane] = wsl[lane]
+            need = max(need, b)
+        ws = None
+        if need:  # zero-filled: the head of the workspace holds the split-K arrival counters
+            ws = torch.zeros((need,), dtype=torch.uint8, device=self.device)
+            plan.bufs["splitk_ws"] = ws
         tname = "bf16" if self.dt == K.VT_BF16 else "f32"
         inserts = []
         for d, info, ops, pos in plan.convs:
-            ws = wsl.get(info["lane"])
             if ws is not None:
-                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), need
             tile = self.lib.vt_conv2d_tile(C.byref(d))
             if tile < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
@@ -559,7 +524,6 @@ class VToonifyEngine:
                 m, cout_t = info["m"], info["cout"]
                 osz = 4 if d.out_dtype == K.VT_F32 else 2
                 rinfo = {"name": "splitk_reduce", "kernel": "conv_splitk_reduce_kernel", "flops": 0,
-                         "lane": info["lane"],
                          "bytes": sk * m * ((cout_t + 7) // 8 * 8) * 4 + m * cout_t * osz}
                 inserts.append((ops, pos, (self.lib.vt_conv2d, (C.byref(d2),), rinfo)))
         # insert the reduce ops right after their slice ops (back to front keeps positions valid)
@@ -641,36 +605,18 @@ class VToonifyEngine:
         return image
 
     def _launch(self, plan: _Plan, with_style: bool, with_gen: bool = True):
-        """Issue the plan's kernels (eager or under graph capture).  Two streams on the GPU: the
-        style path (GEMVs + weight modulation, ~80 us of narrow kernels) runs beside the content
-        encoder and joins before the first AdaIN; in the generator the fusion_skip conv and the RGB
-        skip up-sampling run beside the StyledConvs (see _run)."""
+        """Issue the plan's kernels on the current stream (eager or under graph capture)."""
         stream = self._stream()
-        side = None
-        if self.device.type == "cuda" and self.overlap:
-            if self._side is None:
-                self._side = torch.cuda.Stream(self.device)
-            side = self._side
         xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
         B, cin, H, W = xin.shape
-        if with_style and side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            side.wait_event(ev)
-            self._run(plan.style_ops, C.c_void_p(side.cuda_stream))
-        elif with_style:
-            self._run(plan.style_ops, stream)
         rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()), B, cin,
                                       H * W, K.VT_F32, self.dt, stream)
         _lib.check(rc, "vt_nchw_to_nhwc")
-        self._run(plan.enc_ops[:plan.enc_split], stream)
-        if with_style and side is not None:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            torch.cuda.current_stream(self.device).wait_event(ev)
-        self._run(plan.enc_ops[plan.enc_split:], stream)
+        if with_style:
+            self._run(plan.style_ops, stream)
+        self._run(plan.enc_ops, stream)
         if with_gen:
-            self._run(plan.gen_ops, stream, side)
+            self._run(plan.gen_ops, stream)
 
     def _replay(self, plan: _Plan, with_style: bool):
         """hipGraph replay of the whole frame: ~140 kernel launches become one graph launch
@@ -707,7 +653,7 @@ class VToonifyEngine:
             self._launch_input_only(plan, stream)
             ev[0].record()
             for i, (fn, args, what) in enumerate(ops):
-                rc = 0 if fn is None else fn(*args, stream)   # fork/join markers: timed serially
+                rc = fn(*args, stream)
                 if rc != 0:
                     raise _lib.VtError(f"{self._info(what)['name']} failed: {self.lib.vt_last_error().decode()}")
                 ev[i + 1].record()
