@@ -264,6 +264,7 @@ def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
     assert _conv_case(dev, dtype, 1, 128, 9, 21, 136, 3, 1, 2, 2, act=L, ws=True, expect_kind=1) < t
     assert _conv_case(dev, dtype, 2, 128, 11, 17, 128, 3, 1, 4, 4, resid=True, ws=True, expect_kind=1) < t
     assert _conv_case(dev, dtype, 1, 128, 11, 17, 64, 3, 1, 4, 4, ws=True, expect_kind=0) < t   # cout 64: 1-D
+    assert _conv_case(dev, dtype, 1, 128, 11, 17, 128, 3, 1, 4, 4, ws=False, expect_kind=0) < t  # no workspace: 1-D
     assert _conv_case(dev, dtype, 1, 192, 8, 8, 1, 3, 1, 1, 1, act=K.ACT_RELU_TANH, planar=True, ws=True,
                       expect_kind=1) < t                                                               # mask conv
     # every compiled patch tile, forced by hint (S=0: auto split; S=2 forced)

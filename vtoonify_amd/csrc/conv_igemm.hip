@@ -1156,7 +1156,11 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             if (sk > units_p || a.dil != 1) sk = units_p;   // dilated instances: one chunk per slice
             if (sk > 32) sk = 32;
             t.splitk = (int)sk;
-            if (a.dil != 1 && sk != units_p) t.kind = 0, t.bm = 0, t.splitk = 0;
+            // the dilated instances exist only in the one-chunk-per-slice form: they need the full
+            // split, i.e. a workspace that can hold it -- otherwise run the 1-D kernel
+            const int64_t need_full = (int64_t)units_p * a.M * ((a.coutT + 7) / 8 * 8);
+            if (a.dil != 1 && (sk != units_p || (units_p > 1 && (!a.partial || need_full > ws_floats_avail))))
+                t.kind = 0, t.bm = 0, t.splitk = 0;
         } else if (a.dil == 1 && a.coutT >= 64) {
             t.bm = 128, t.bn = 64;
         } else {
