@@ -135,6 +135,15 @@ typedef struct vt_conv_desc {
     const float* slope_vec; /* optional per-output-channel negative slope [cout] for VT_ACT_LRELU
                               (nn.PReLU of the pSp encoder, model/encoder/encoders/helpers.py:97-119);
                               NULL = the scalar `slope` */
+    /* Fused ToRGB (model/stylegan/model.py:383-392) for a same-resolution StyledConv whose tile holds
+     * all `cout` channels (vt_conv2d_tile: BN >= cout, no split-K; VT_ERR_UNSUPPORTED otherwise):
+     *   rgb_out[n][j][p] = sum_c rgb_weight[j][c] * out_fp32[n][p][c] + rgb_bias[j] + rgb_resid[n][j][p]
+     * rgb_weight: packed [3][1][cout] in `dtype` (vt_modulate_weight of the ToRGB layer, no demod);
+     * rgb_out / rgb_resid: planar fp32 (n,3,out_h,out_w), may alias.  NULL rgb_weight = off. */
+    const void* rgb_weight;
+    const float* rgb_bias;
+    const float* rgb_resid;
+    float* rgb_out;
     int32_t splitk_phase;  /* two-pass split-K only: 0 = slices + reduce (default), 1 = launch the K
                               slices only, 2 = launch the reduce pass only (lets a caller time or
                               schedule the two kernels separately) */

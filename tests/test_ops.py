@@ -280,6 +280,49 @@ def test_conv_direct_to_lds_and_patch_kernels(dev, dtype):
     assert _conv_case(dev, dtype, 2, 64, 9, 7, 3, 1, 1, 0, 1, planar=True, resid=True, ws=True) < t    # 1x1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fused_torgb(dev, dtype):
+    """StyledConv + ToRGB in one launch (vt_conv_desc.rgb_*): rgb = W_rgb . act(conv) + bias + skip, for
+    every kernel family / wave layout that can hold all channels in one tile; refused otherwise."""
+    g = np.random.default_rng(12)
+    tol = F32_TOL if dtype == torch.float32 else 1.5e-2
+    for cin, cout, H, W, hint in [(64, 128, 19, 37, P + 1000000 + 256128),      # patch, 8 waves, channels over 2 waves
+                                  (64, 64, 21, 35, P + 1000000 + 256064),
+                                  (64, 64, 9, 40, P + 1000000 + 128064),
+                                  (32, 32, 17, 33, 0),                          # register-staged 128x32 (4 waves x 1)
+                                  (64, 128, 12, 20, 2 * P + 1000000 + 128128)]:  # 1-D direct-to-LDS, 2x2 waves
+        x = g.standard_normal((2, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(9 * cin)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        wr = (g.standard_normal((3, cout, 1, 1)) / math.sqrt(cout)).astype(np.float32)
+        br = g.standard_normal(3).astype(np.float32)
+        skip = g.standard_normal((2, 3, H, W)).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        wrp = K.pack_conv_weight(T(wr, dev), out_dtype=dtype)
+        xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        wrq = wrp.float().cpu().numpy().reshape(3, 1, 1, cout).transpose(0, 3, 1, 2)
+        y_ref = O.leaky_relu(O.conv2d(xq, wq, b, 1, 1, 1), 0.2) * np.float32(2 ** 0.5)
+        rgb_ref = O.conv2d(y_ref, wrq, br) + skip
+        out = torch.zeros((2, H, W, cout), dtype=dtype, device=dev)
+        rgb = T(skip.copy(), dev)
+        K.conv2d(src0=xt, c0=cin, ld0=cin, n=2, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
+                 bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dtype),
+                 tile_hint=hint, rgb_weight=wrp, rgb_bias=T(br, dev), rgb_resid=rgb, rgb_out=rgb)
+        assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), y_ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
+        assert rel_err(rgb.cpu().numpy(), rgb_ref) < tol, (cin, cout, hint)
+    # more channels than one tile: refused (the engine then issues ToRGB as its own conv)
+    xt = K.nchw_to_nhwc(T(g.standard_normal((1, 64, 8, 8)).astype(np.float32), dev), dtype)
+    wp = K.pack_conv_weight(T((g.standard_normal((256, 64, 3, 3)) / 24).astype(np.float32), dev), out_dtype=dtype)
+    wrp = K.pack_conv_weight(T((g.standard_normal((3, 256, 1, 1)) / 16).astype(np.float32), dev), out_dtype=dtype)
+    rgb = torch.zeros((1, 3, 8, 8), device=dev)
+    with pytest.raises(Exception, match="fused ToRGB"):
+        K.conv2d(src0=xt, c0=64, ld0=64, n=1, h=8, w=8, out_h=8, out_w=8, weight=wp, cout=256, kh=3, kw=3, pad=1,
+                 out=torch.zeros((1, 8, 8, 256), dtype=dtype, device=dev), ld_out=256, dtype=K.dt_code(dtype),
+                 rgb_weight=wrp, rgb_out=rgb)
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
         ("tile_hint", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("slope_vec", C.c_void_p),
+        ("rgb_weight", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_resid", C.c_void_p), ("rgb_out", C.c_void_p),
         ("splitk_phase", C.c_int32),
     ]
 

@@ -48,6 +48,10 @@ struct ConvArgs {
     const void* wgt;
     const float* bias;
     const float* slope_vec;
+    const void* rgb_w;       // fused ToRGB: packed [3][cout] weights (compute dtype) or NULL
+    const float* rgb_bias;
+    const float* rgb_resid;
+    float* rgb_out;
     const float* alpha_dev;
     const float* in_scale;
     const float* in_shift;
@@ -351,16 +355,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         // fall through to the fused epilogue below
     }
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    // Fused ToRGB (model/stylegan/model.py:383-392): when this tile holds ALL output channels of its
+    // pixels, the 1x1 modulated conv C -> 3 that follows a same-resolution StyledConv is three dot
+    // products over values that are already in registers -- the C-channel activation (67 MB at the
+    // 1024^2 level) is not read back from HBM by a separate ToRGB launch.
+    const bool rgbf = p.rgb_w != nullptr;
+    float rp[TM][3];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) rp[a][0] = rp[a][1] = rp[a][2] = 0.0f;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
-        float bv[4], sv[4];
+        float bv[4], sv[4], wr[3][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nn = n + i;
             const int co = (p.phases > 1) ? nn % p.cout : nn;
             bv[i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
             sv[i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                wr[j][i] = (rgbf && nn < p.coutT) ? to_f32(((const T*)p.rgb_w)[j * p.coutT + nn]) : 0.0f;
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -369,7 +384,62 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             float f[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, acc[a][b][i], bv[i], ga, sv[i]);
+            if (rgbf) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    rp[a][j] += (f[0] * wr[j][0] + f[1] * wr[j][1]) + (f[2] * wr[j][2] + f[3] * wr[j][3]);
+            }
             store_out4(p, m, n, f);
+        }
+    }
+    if (!rgbf) return;
+    // sum the partial dot products over the 4 lane groups (channels 4q..4q+3 of every fragment) ...
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = rp[a][j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            rp[a][j] = v;
+        }
+    // ... and over the WN wavefronts that split the channels (through LDS, fixed order)
+    if (WN > 1) {
+        float* xs = reinterpret_cast<float*>(smem);
+        __syncthreads();   // every wave is done with the tile buffers
+        if (q == 0) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xs[((wn * WM + wm) * (TM * 16) + a * 16 + l15) * 3 + j] = rp[a][j];
+        }
+        __syncthreads();
+        if (wn == 0 && q == 0) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float v = rp[a][j];
+                    for (int w2 = 1; w2 < WN; ++w2) v += xs[((w2 * WM + wm) * (TM * 16) + a * 16 + l15) * 3 + j];
+                    rp[a][j] = v;
+                }
+        }
+    }
+    if (wn == 0 && q == 0) {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+            if (m < 0) continue;
+            const int img = m / HoWo;
+            const int rem = m - img * HoWo;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int64_t off = ((int64_t)img * 3 + j) * HoWo + rem;
+                float v = rp[a][j] + (p.rgb_bias ? p.rgb_bias[j] : 0.0f);
+                if (p.rgb_resid) v += p.rgb_resid[off];
+                p.rgb_out[off] = v;
+            }
         }
     }
 }
@@ -1250,6 +1320,11 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
     const TilePlan t = choose_plan<T>(a, hint % 1000000000, ws_floats);
     a.splitk = t.splitk;
     a.ldp = (a.coutT + 7) / 8 * 8;
+    if (a.rgb_w && (t.bn < a.coutT || t.splitk > 1)) {
+        vt_set_error("vt_conv2d: fused ToRGB needs all %d output channels in one tile (plan %dx%d, split %d)",
+                     a.coutT, t.bm, t.bn, t.splitk);
+        return VT_ERR_UNSUPPORTED;
+    }
     if (t.kind == 1) {
         GldsArgs g;
         if (!patch_eligible<T>(a, g)) {
@@ -1316,12 +1391,18 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
                    (int64_t)d->n * d->out_h * d->out_w * (d->phases == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "vt_conv2d: tensor too large for 32-bit pixel indices");
 
+    VT_REQUIRE(!d->rgb_weight || (d->rgb_out && d->phases == 1 && d->out_layout == VT_OUT_NHWC && !d->transposed),
+               "vt_conv2d: fused ToRGB needs rgb_out, phases == 1 and NHWC output");
     memset(&a, 0, sizeof(a));
     a.src0 = d->src0;
     a.src1 = d->src1;
     a.wgt = d->weight;
     a.bias = d->bias;
     a.slope_vec = d->slope_vec;
+    a.rgb_w = d->rgb_weight;
+    a.rgb_bias = d->rgb_bias;
+    a.rgb_resid = d->rgb_resid;
+    a.rgb_out = d->rgb_out;
     a.alpha_dev = d->alpha_dev;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;

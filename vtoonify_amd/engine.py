@@ -76,6 +76,7 @@ class VToonifyEngine:
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
+        self.fuse_torgb = True
         self._style_key = None
         self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.g = "generator.generator." if self.dual else "generator."
@@ -474,16 +475,24 @@ class VToonifyEngine:
                               w=w, out_h=h, out_w=w, weight=wm1, cout=c1o, kh=3, kw=3, pad=1, phases=4,
                               bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
                               out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
-                self._op_conv(ops, plan, src0=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
-                              h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm2, cout=c1o, kh=3, kw=3, pad=1,
-                              bias=sd[f"{g}{n2}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
-                              out=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
-                # ToRGB: 1x1 modulated conv (no demod) + bias + up-sampled skip (model.py:383-392)
-                self._op_conv(ops, plan, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
-                              h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
-                              bias=self.w[f"{n3}.bias"], beta=1.0, resid=rgb.data_ptr() + b0 * 3 * 4 * hw * 4,
-                              out=rgb.data_ptr() + b0 * 3 * 4 * hw * 4, ld_out=0, out_layout=OUT_NCHW,
-                              out_dtype=K.VT_F32)
+                same_kw = dict(src0=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
+                               h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm2, cout=c1o, kh=3, kw=3, pad=1,
+                               bias=sd[f"{g}{n2}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
+                               out=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
+                rgb_ptr = rgb.data_ptr() + b0 * 3 * 4 * hw * 4
+                rgb_kw = dict(rgb_weight=wm3, rgb_bias=self.w[f"{n3}.bias"], rgb_resid=rgb_ptr, rgb_out=rgb_ptr)
+                # ToRGB (1x1 modulated conv, no demod, + bias + up-sampled skip; model.py:383-392) is
+                # fused into the StyledConv's epilogue when one tile holds all its channels
+                probe = K.make_conv_desc(dtype=self.dt, **same_kw, **rgb_kw)
+                probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
+                tile = self.lib.vt_conv2d_tile(C.byref(probe))
+                fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
+                self._op_conv(ops, plan, **same_kw, **(rgb_kw if fuse_rgb else {}))
+                if not fuse_rgb:
+                    self._op_conv(ops, plan, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
+                                  h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
+                                  bias=self.w[f"{n3}.bias"], beta=1.0, resid=rgb_ptr, out=rgb_ptr, ld_out=0,
+                                  out_layout=OUT_NCHW, out_dtype=K.VT_F32)
             out, co, skip, h, w = o2, c1o, rgb, 2 * h, 2 * w
         plan.image = skip
         self._finalize_convs(plan)
