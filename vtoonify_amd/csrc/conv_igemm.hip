@@ -373,9 +373,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             const int co = (p.phases > 1) ? nn % p.cout : nn;
             bv[i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
             sv[i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
+        }
+        if (rgbf) {   // wave-uniform: convs without the fusion pay one scalar branch per fragment column
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                wr[j][i] = (rgbf && nn < p.coutT) ? to_f32(((const T*)p.rgb_w)[j * p.coutT + nn]) : 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                const int nc = (n + i < p.coutT) ? n + i : p.coutT - 1;   // clamped: loads stay unconditional
+                const float live = (n + i < p.coutT) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) wr[j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
+            }
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
