@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -76,7 +77,7 @@ class VToonifyEngine:
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
-        self.fuse_torgb = True
+        self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
         self._style_key = None
         self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.g = "generator.generator." if self.dual else "generator."
