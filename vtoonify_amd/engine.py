@@ -658,6 +658,13 @@ class VToonifyEngine:
         stream = self._stream()
         n = len(ops)
         acc = [0.0] * n
+        # calibrate the cost of an event pair with nothing between (subtracted from every op)
+        cal = [torch.cuda.Event(enable_timing=True) for _ in range(65)]
+        for e in cal:
+            e.record()
+        torch.cuda.synchronize(self.device)
+        gaps = sorted(cal[i].elapsed_time(cal[i + 1]) for i in range(64))
+        overhead = gaps[len(gaps) // 2]
         for _ in range(iters):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
             self._launch_input_only(plan, stream)
@@ -669,7 +676,7 @@ class VToonifyEngine:
                 ev[i + 1].record()
             torch.cuda.synchronize(self.device)
             for i in range(n):
-                acc[i] += ev[i].elapsed_time(ev[i + 1])
+                acc[i] += max(ev[i].elapsed_time(ev[i + 1]) - overhead, 0.0)
         return [(self._info(ops[i][2]), acc[i] / iters) for i in range(n)]
 
     def _launch_input_only(self, plan: _Plan, stream):
