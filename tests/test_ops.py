@@ -323,6 +323,25 @@ def test_conv_fused_torgb(dev, dtype):
                  rgb_weight=wrp, rgb_out=rgb)
 
 
+def test_conv_c32_persistent_kernel(dev, monkeypatch):
+    """3x3 32->32 bf16 (the 1024^2 level) runs the persistent register-weight kernel: several tiles per
+    workgroup (double-buffered patches), image borders, batch, residual epilogue."""
+    t = 8e-3
+    import ctypes
+    from vtoonify_amd import _lib
+    monkeypatch.setenv("VT_C32_BLOCKS", "3")     # 2 x 3 x 4 = 24 tiles over 3 workgroups
+    assert _conv_case(dev, torch.bfloat16, 2, 32, 37, 50, 32, 3, 1, 1, 1, act=K.ACT_LRELU, resid=True) < t
+    monkeypatch.delenv("VT_C32_BLOCKS")
+    assert _conv_case(dev, torch.bfloat16, 1, 32, 16, 16, 32, 3, 1, 1, 1) < t
+    x = K.nchw_to_nhwc(torch.zeros(1, 32, 16, 16, device=dev), torch.bfloat16)
+    d = K.make_conv_desc(src0=x, c0=32, ld0=32, n=1, h=16, w=16, out_h=16, out_w=16, weight=x, cout=32, kh=3, kw=3,
+                         pad=1, out=x, ld_out=32, dtype=K.VT_BF16)
+    assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == 3
+    # fp32 (parity mode) and dilated / strided 32->32 convs stay on the generic kernels
+    assert _conv_case(dev, torch.float32, 1, 32, 19, 21, 32, 3, 1, 1, 1, act=K.ACT_LRELU) < F32_TOL
+    assert _conv_case(dev, torch.bfloat16, 1, 32, 19, 21, 32, 3, 2, 1, 1) < t
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

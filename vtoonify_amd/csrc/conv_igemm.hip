@@ -1003,6 +1003,111 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
     conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split, tile_n * p.tiles_m + tile_m);
 }
 
+// ---------------------------------------------------------------------------------------
+// 3x3, Cin = Cout = 32, stride 1: the 1024x1024 level of the generator (convs.15) -- 19 GFLOP on
+// 134 MB of activations, HBM-bound (144 flop/B < the 312 flop/B ridge).  Everything that is not
+// the activation stream is taken off the memory path:
+//   * the whole weight tensor (32 x 9 x 32 bf16 = 18 KB) lives in REGISTERS for the life of the
+//     workgroup (18 MFMA B-fragments per lane, loaded once);
+//   * workgroups are PERSISTENT: each loops over 16x16-pixel tiles, the next tile's input patch
+//     (18x18 pixels x 64 B, direct-to-LDS with zero fill at the image border) is in flight while
+//     the current tile runs its 9 taps -- no per-tile prologue, one barrier pair per tile;
+//   * a pixel's 32 channels are one 64-byte LDS row; a tap's A fragment is one ds_read_b128 per
+//     16 pixels (4x4 XOR swizzle of the 16-byte slots), feeding 2 MFMAs (16x16x32);
+//   * epilogue (bias, LeakyReLU, fused ToRGB) from registers.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
+    static_assert(sizeof(T) == 2, "bf16 only (64-byte pixel rows)");
+    constexpr int TH = 16, TW = 16, BM = 256, BN = 32, WM = 4, WN = 1;
+    constexpr int TM = 4, TN = 2;
+    constexpr int PH = TH + 2, PW = TW + 2, PROWS = PH * PW;   // 324 patch pixels
+    constexpr int PA = ((PROWS + 15) / 16 + 3) / 4;              // 16-pixel loads per wave per tile: 6
+    constexpr int A_BYTES = PA * 4 * 1024;                       // 24 KB per buffer
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & 3;
+    const int wm = wave;
+    const int q = lane >> 4, l15 = lane & 15;
+    // 4x4 swizzle of the four 16-byte slots of a 64-byte row: conflict-free for the ds_read_b128
+    // lane groups when 16 consecutive pixels are read (slot' = slot ^ G[(pixel >> 2) & 3])
+    auto swz = [](int pr) -> int { return (0x1320 >> (((pr >> 2) & 3) * 4)) & 3; };   // G = {0,2,3,1}
+
+    // ---- weights -> registers: fragment (tap, b): row n = b*16 + l15, k = q*8 .. q*8+7 ----------
+    u128 wreg[9][TN];
+    {
+        const T* wg = (const T*)p.wgt;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) wreg[t][b] = ld128(wg + (int64_t)(b * 16 + l15) * p.K + t * 32 + q * 8);
+    }
+    const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int ntiles = p.N * tiles_x * tiles_y;
+    const int lpix = lane >> 2, lchunk = lane & 3;
+
+    auto issue = [&](int tile, int buf) {
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int pr = (i * 4 + wave) * 16 + lpix;
+            const int py = pr / PW, px = pr - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
+            const uint32_t off = in ? pix * (uint32_t)(p.ld0 * 2) + ((lchunk ^ swz(pr)) << 4) : GLDS_OOB;
+            vt_glds16(r0, smem + buf * A_BYTES + (i * 4 + wave) * 1024, off, 0u);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue(tile, 0);
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            issue(next, buf ^ 1);
+            vt_glds_wait_n<PA>();      // this tile's patch has landed, the next one may be in flight
+        } else {
+            vt_glds_wait_n<0>();
+        }
+        vt_lds_barrier();
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sa = smem + buf * A_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            u128 fa[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int pr = (wm * TM + a + ky) * PW + kx + l15;
+                fa[a] = ld128(sa + pr * 64 + ((q ^ swz(pr)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], wreg[t][b], fa[a]);
+        }
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, 0, 0, 0);
+        vt_lds_barrier();   // every wave is done reading `buf` before the next issue overwrites it
+        buf ^= 1;
+    }
+}
+
 // Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
 // then the same bias / activation / gain / residual / layout epilogue as the fused kernel.
 // One thread per (GEMM row, 8 output columns).
@@ -1190,6 +1295,19 @@ static bool patch_eligible(const ConvArgs& a, GldsArgs& g) {
 }
 
 template <typename T>
+static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
+    if (sizeof(T) != 2 || a.force_generic || a.transposed || a.in_scale) return false;
+    if (a.taps != 9 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return false;
+    if (a.c0 != 32 || a.c1 != 0 || a.cout != 32 || a.phases != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.splitk > 1) return false;
+    const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * 2;
+    if (n0 >= (((int64_t)1 << 31) - 4096)) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrec1 = g.nrecw = g.bias0 = g.bias1 = 0;
+    return true;
+}
+
+template <typename T>
 static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     TilePlan t;
@@ -1204,6 +1322,13 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         return (int64_t)vt_cdiv(a.Ho, th) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, n);
     };
     GldsArgs g;
+    if (hp != 2 && hbm == 0 && c32_eligible<T>(a, g)) {   // the 1024^2 level: persistent register-weight kernel
+        t.kind = 3;
+        t.bm = 256;
+        t.bn = 32;
+        t.splitk = 1;
+        return t;
+    }
     const bool can_patch = hp != 2 && patch_eligible<T>(a, g);
     int units = 0;  // K units that can be split: K-steps (1-D) or channel chunks (patch)
     if (hbm > 0) {
@@ -1320,6 +1445,27 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
 }
 
 template <typename T>
+int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    ConvArgs args = a;
+    args.splitk = 1;
+    args.tiles_n = 1;
+    args.tiles_m = a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16);
+    int blocks = args.tiles_m < 768 ? args.tiles_m : 768;   // persistent: 3 workgroups per CU
+    if (const char* e = getenv("VT_C32_BLOCKS")) {          // tests: force several tiles per workgroup
+        const int v = atoi(e);
+        if (v > 0 && v < blocks) blocks = v;
+    }
+#ifdef VT_EMU
+    auto k = conv3x3_c32_kernel<bf16_t>;
+#else
+    auto k = conv3x3_c32_kernel<bf16_t>;
+#endif
+    (void)sizeof(T);
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    return vt_check_launch("vt_conv2d(c32)");
+}
+
+template <typename T>
 int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) {
     ConvArgs a = a0;
     a.force_generic = hint >= 1000000000;
@@ -1330,6 +1476,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         vt_set_error("vt_conv2d: fused ToRGB needs all %d output channels in one tile (plan %dx%d, split %d)",
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
+    }
+    if (t.kind == 3) {
+        GldsArgs g;
+        if (!c32_eligible<T>(a, g)) {
+            vt_set_error("vt_conv2d: c32 kernel requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+        return launch_c32<T>(a, g, stream);
     }
     if (t.kind == 1) {
         GldsArgs g;

@@ -521,7 +521,8 @@ class VToonifyEngine:
             if tile < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
-            kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel"}[kind]
+            kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
+                     3: "conv3x3_c32_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1:
