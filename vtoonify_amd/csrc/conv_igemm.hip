@@ -1017,7 +1017,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
 //   * epilogue (bias, LeakyReLU, fused ToRGB) from registers.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // 2 waves per SIMD = 2 workgroups per CU (<= 256 registers)
 conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(sizeof(T) == 2, "bf16 only (64-byte pixel rows)");
     constexpr int TH = 16, TW = 16, BM = 256, BN = 32, WM = 4, WN = 1;
@@ -1098,11 +1098,68 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], wreg[t][b], fa[a]);
+            vt_sched_fence();   // keep one tap's fragments live at a time (the scheduler otherwise
+                                // hoists all 36 reads: 376 registers, occupancy 1)
         }
         const int img = tile / (tiles_x * tiles_y);
         const int trem = tile - img * (tiles_x * tiles_y);
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-        conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, 0, 0, 0);
+        // lean epilogue (the generic one costs ~200 registers next to the resident weights):
+        // bias + LeakyReLU * gain -> bf16 NHWC (8-byte stores), optional fused ToRGB
+        {
+            const PatchRows<TW> rowmap{img, y0, x0, p.Ho, p.Wo};
+            const float ga = p.gain_alpha;
+            const bool rgbf = p.rgb_w != nullptr;
+            const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int n = b * 16 + q * 4;
+                    float f[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[a][b][i] + (p.bias ? p.bias[n + i] : 0.0f);
+                        if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
+                        f[i] = v * ga;
+                    }
+                    if (rgbf) {
+                        const T* rw = (const T*)p.rgb_w + n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            r0 += f[i] * to_f32(rw[i]);
+                            r1 += f[i] * to_f32(rw[32 + i]);
+                            r2 += f[i] * to_f32(rw[64 + i]);
+                        }
+                    }
+                    if (m >= 0) {
+                        u64v v;
+                        v.x = pack_bf16x2(f[0], f[1]);
+                        v.y = pack_bf16x2(f[2], f[3]);
+                        *reinterpret_cast<u64v*>((bf16_t*)p.out + (int64_t)m * p.ld_out + n) = v;
+                    }
+                }
+                if (rgbf) {
+                    r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
+                    r1 += __shfl_xor(r1, 16, 64); r1 += __shfl_xor(r1, 32, 64);
+                    r2 += __shfl_xor(r2, 16, 64); r2 += __shfl_xor(r2, 32, 64);
+                    if (q == 0 && m >= 0) {
+                        const int im = m / HoWo;
+                        const int64_t o0 = (int64_t)im * 3 * HoWo + (m - im * HoWo);
+                        const float rr[3] = {r0, r1, r2};
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int64_t off = o0 + (int64_t)j * HoWo;
+                            float v = rr[j] + (p.rgb_bias ? p.rgb_bias[j] : 0.0f);
+                            if (p.rgb_resid) v += p.rgb_resid[off];
+                            p.rgb_out[off] = v;
+                        }
+                    }
+                }
+            }
+        }
         vt_lds_barrier();   // every wave is done reading `buf` before the next issue overwrites it
         buf ^= 1;
     }
@@ -1300,6 +1357,9 @@ static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
     if (a.taps != 9 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return false;
     if (a.c0 != 32 || a.c1 != 0 || a.cout != 32 || a.phases != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.splitk > 1) return false;
+    // lean epilogue: bf16 NHWC vector stores, bias + (Leaky)ReLU * gain, optional fused ToRGB
+    if (a.out_layout != VT_OUT_NHWC || a.out_f32 || !a.vec_store || a.resid || a.slope_vec || a.alpha_dev) return false;
+    if (a.act != VT_ACT_NONE && a.act != VT_ACT_LRELU) return false;
     const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * 2;
     if (n0 >= (((int64_t)1 << 31) - 4096)) return false;
     g.nrec0 = (uint32_t)n0;
@@ -1450,7 +1510,7 @@ int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     args.splitk = 1;
     args.tiles_n = 1;
     args.tiles_m = a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16);
-    int blocks = args.tiles_m < 768 ? args.tiles_m : 768;   // persistent: 3 workgroups per CU
+    int blocks = args.tiles_m < 512 ? args.tiles_m : 512;   // persistent: 2 workgroups per CU
     if (const char* e = getenv("VT_C32_BLOCKS")) {          // tests: force several tiles per workgroup
         const int v = atoi(e);
         if (v > 0 && v < blocks) blocks = v;

@@ -216,6 +216,13 @@ __device__ __forceinline__ void vt_ticket_store(int* p, int v) {
 #endif
 
 #ifdef VT_EMU
+static inline void vt_sched_fence() {}
+#else
+// scheduling fence: the compiler may not move instructions across it
+__device__ __forceinline__ void vt_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+#ifdef VT_EMU
 struct BufRsrc {
     const char* base;
     uint32_t nrec;
