@@ -232,8 +232,9 @@ int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
                     const void* absdiff_other, int ld_other, const float* scale,
                     const float* shift, int n, int hw, int c, int dtype, vt_stream stream);
 
-/* Fusion glue (model/vtoonify.py:127, 259): out[p] = [skip(3) | 0 x5 | f_e[p][:] * m[p]]
- * with per-pixel stride ld_out >= 8 + c.  skip is NCHW fp32 (n,3,h,w); mask (n,h,w) fp32
+/* Fusion glue (model/vtoonify.py:127, 259): out[p] = [skip(3) | zeros | f_e[p][:] * m[p]] with
+ * per-pixel stride ld_out = header + c, header = 8, 16, ... channels (64 makes the consumer's
+ * channel count a multiple of the direct-to-LDS K-step).  skip is NCHW fp32 (n,3,h,w); mask (n,h,w) fp32
  * (NULL = 1, the Toonify backbone, vtoonify.py:262). */
 int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float* mask,
                    const float* skip, int n, int hw, int c, int dtype, vt_stream stream);

@@ -308,7 +308,9 @@ fusion_pack_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ f_e, i
                    int c) {
     constexpr int VEC = 16 / sizeof(T);
     const int cvn = c / VEC;
-    const int hv = 8 / VEC;  // header vectors: 8 channels [skip(3) | 0 x5]
+    const int hdr = ld_out - c;   // header channels [skip(3) | zeros]: 8, or 64 so that the consumer's
+                                  // channel count is a multiple of the direct-to-LDS K-step
+    const int hv = hdr / VEC;
     const int per_px = cvn + hv;
     const int64_t total = (int64_t)n * hw * per_px;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -333,7 +335,7 @@ fusion_pack_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ f_e, i
             unpack16<T>(ld128(f_e + pix * ld_e + cv * VEC), f);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) f[k] *= m;
-            st128(o + 8 + cv * VEC, pack16<T>(f));
+            st128(o + hdr + cv * VEC, pack16<T>(f));
         }
     }
 }
@@ -536,14 +538,15 @@ extern "C" int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
 extern "C" int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float* mask,
                               const float* skip, int n, int hw, int c, int dtype, vt_stream stream) {
     VT_REQUIRE(out && f_e && skip, "vt_fusion_pack: null tensor");
-    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ld_out >= c + 8, "vt_fusion_pack: bad sizes");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ld_out >= c + 8 && (ld_out - c) % 8 == 0,
+               "vt_fusion_pack: bad sizes (ld_out = header + c, header a multiple of 8, >= 8)");
     if (dtype == VT_F32) {
-        const int64_t total = (int64_t)n * hw * (c / 4 + 2);
+        const int64_t total = (int64_t)n * hw * (ld_out / 4);
         auto k = fusion_pack_kernel<float>;
         VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, (const float*)f_e, ld_e,
                   mask, skip, n, hw, c);
     } else if (dtype == VT_BF16) {
-        const int64_t total = (int64_t)n * hw * (c / 8 + 1);
+        const int64_t total = (int64_t)n * hw * (ld_out / 8);
         auto k = fusion_pack_kernel<bf16_t>;
         VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (bf16_t*)out, ld_out, (const bf16_t*)f_e, ld_e,
                   mask, skip, n, hw, c);

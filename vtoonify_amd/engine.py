@@ -35,6 +35,9 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC
 SQRT2 = math.sqrt(2.0)
 N_LATENT = 18
 _DIL = {1: 4, 2: 4, 3: 2, 4: 2, 5: 1, 6: 1}  # model/vtoonify.py:201-207
+# header of the fusion operand [skip(3) | zeros | f_E * m_E]: 64 channels so that the fusion_skip conv
+# (Cin = header + C) has a channel count the direct-to-LDS / patch kernels accept
+FEM_HDR = 64
 
 
 def _pad8(c: int) -> int:
@@ -114,9 +117,9 @@ class VToonifyEngine:
                 self.w[f"fusion_out.{fi}"] = K.pack_conv_weight(sd[f"fusion_out.{fi}.weight"], out_dtype=T)
             wsk = sd[f"fusion_skip.{fi}.weight"]  # (3, C+3, 3, 3): cat[skip(3), f_E(*m)]
             c = wsk.shape[1] - 3
-            cmap = torch.tensor([0, 1, 2, -1, -1, -1, -1, -1] + list(range(3, c + 3)), dtype=torch.int32,
+            cmap = torch.tensor([0, 1, 2] + [-1] * (FEM_HDR - 3) + list(range(3, c + 3)), dtype=torch.int32,
                                 device=self.device)
-            self.w[f"fusion_skip.{fi}"] = K.pack_conv_weight(wsk, cin_dst=c + 8, chan_map=cmap, out_dtype=T)
+            self.w[f"fusion_skip.{fi}"] = K.pack_conv_weight(wsk, cin_dst=c + FEM_HDR, chan_map=cmap, out_dtype=T)
         # modulated conv weights stay fp32 (cout, cin, k, k); they are re-modulated per style
         self.modw = {}
         for i in range(6, 16):
@@ -408,7 +411,7 @@ class VToonifyEngine:
             if lvl < self.n_fuse:
                 f_e, ce, he, we = feats[lvl]
                 assert (he, we) == (h, w) and ce == co, "encoder/generator size mismatch (H, W must be multiples of 8)"
-                fem = self._buf(plan, f"fem{lvl}", (B, h, w, co + 8))
+                fem = self._buf(plan, f"fem{lvl}", (B, h, w, co + FEM_HDR))
                 mask = None
                 if self.dual:
                     # Fusion.forward (vtoonify.py:122-128)
@@ -436,18 +439,18 @@ class VToonifyEngine:
                                   out_layout=OUT_NCHW, out_dtype=K.VT_F32)
                     plan.masks.append(mask)
                 ops.append((lib.vt_fusion_pack,
-                            (C.c_void_p(fem.data_ptr()), co + 8, C.c_void_p(f_e.data_ptr()), co,
+                            (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
                              C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
                              B, hw, co, dt),
                             {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0,
-                             "bytes": B * hw * (co * self.esz + (co + 8) * self.esz + 16)}))
+                             "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
-                self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + 8 * self.esz, c1=co,
-                              ld1=co + 8, n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[wkey], cout=co, kh=3,
+                self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + FEM_HDR * self.esz, c1=co,
+                              ld1=co + FEM_HDR, n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[wkey], cout=co, kh=3,
                               kw=3, pad=1, bias=sd[wkey + ".bias"], out=fo, ld_out=co)
                 sk2 = self._buf(plan, f"fskip{lvl}", (B, 3, h, w), f32)
-                self._op_conv(ops, plan, src0=fem, c0=co + 8, ld0=co + 8, n=B, h=h, w=w, out_h=h, out_w=w,
+                self._op_conv(ops, plan, src0=fem, c0=co + FEM_HDR, ld0=co + FEM_HDR, n=B, h=h, w=w, out_h=h, out_w=w,
                               weight=self.w[f"fusion_skip.{lvl}"], cout=3, kh=3, kw=3, pad=1,
                               bias=sd[f"fusion_skip.{lvl}.bias"], out=sk2, ld_out=0, out_layout=OUT_NCHW,
                               out_dtype=K.VT_F32)
