@@ -147,6 +147,11 @@ typedef struct vt_conv_desc {
     int32_t splitk_phase;  /* two-pass split-K only: 0 = slices + reduce (default), 1 = launch the K
                               slices only, 2 = launch the reduce pass only (lets a caller time or
                               schedule the two kernels separately) */
+    void* stats_part;      /* NULL, or vt_instnorm_ws_bytes(n, out_h*out_w, cout) bytes that receive the
+                              InstanceNorm chunk records of the tensor this conv writes (NHWC output in
+                              the compute dtype, phases == 1): the split-K reduce pass emits them while
+                              it writes the output, any other plan appends the statistics launch.
+                              Consumer: vt_instnorm_apply_stats. */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
@@ -227,6 +232,11 @@ int vt_instnorm_stats(float* scale, float* shift, const void* x, int ld_x,
  * vt_affine_apply). */
 int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
                       const float* style_gb, int ld_gb, void* partials, int dtype, vt_stream stream);
+/* The second launch of vt_instnorm_apply alone, on chunk records a conv already wrote
+ * (vt_conv_desc.stats_part). */
+int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
+                            const float* style_gb, int ld_gb, const void* partials, int dtype,
+                            vt_stream stream);
 /* out[p][c] = x*scale+shift  (and the |x-other| half when absdiff_other != NULL). */
 int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
                     const void* absdiff_other, int ld_other, const float* scale,

@@ -343,6 +343,54 @@ def test_conv_c32_persistent_kernel(dev, monkeypatch):
     assert _conv_case(dev, torch.bfloat16, 1, 32, 19, 21, 32, 3, 2, 1, 1) < t
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_emits_instnorm_records(dev, dtype):
+    """vt_conv_desc.stats_part: the split-K reduce pass writes the InstanceNorm chunk records of the
+    tensor it stores (else the statistics launch is appended) -- AdaIN from those records is
+    BIT-identical to AdaIN from the stand-alone statistics pass over the stored tensor."""
+    import ctypes as C
+    from vtoonify_amd import _lib
+    g = np.random.default_rng(21)
+    N, Ci, H, W, Co = 2, 128, 9, 11, 48
+    x = g.standard_normal((N, Ci, H, W)).astype(np.float32)
+    r = g.standard_normal((N, Co, H, W)).astype(np.float32)
+    w = (g.standard_normal((Co, Ci, 3, 3)) / 30).astype(np.float32)
+    b = g.standard_normal(Co).astype(np.float32)
+    gb = g.standard_normal((N, 2 * Co)).astype(np.float32)
+    code = K.dt_code(dtype)
+    xt, rt = K.nchw_to_nhwc(T(x, dev), dtype), K.nchw_to_nhwc(T(r, dev), dtype)
+    wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+    wsk = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+    lib = _lib.lib()
+    hw = H * W
+    gbt = T(gb, dev)
+    for ws in (wsk, None):           # split-K (records from the reduce pass) / one pass (launch appended)
+        out = torch.zeros((N, H, W, Co), dtype=dtype, device=dev)
+        part = torch.zeros(K.instnorm_ws_bytes(N, hw, Co), dtype=torch.uint8, device=dev)
+        d = K.make_conv_desc(src0=xt, c0=Ci, ld0=Ci, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=Co, kh=3, kw=3,
+                             pad=1, bias=T(b, dev), act=K.ACT_LRELU, alpha=0.7, beta=0.7, resid=rt, ld_res=Co,
+                             out=out, ld_out=Co, dtype=code, splitk_ws=ws, stats_part=part)
+        if ws is not None:
+            assert (lib.vt_conv2d_tile(C.byref(d)) // 1000000) % 100 > 1     # really split
+        assert lib.vt_conv2d(C.byref(d), K._stream(xt)) == 0, lib.vt_last_error()
+        a = torch.zeros_like(out)
+        assert lib.vt_instnorm_apply_stats(a.data_ptr(), Co, out.data_ptr(), Co, N, hw, Co, gbt.data_ptr(), 2 * Co,
+                                           part.data_ptr(), code, K._stream(xt)) == 0
+        ref = torch.zeros_like(out)
+        part2 = torch.zeros_like(part)
+        assert lib.vt_instnorm_apply(ref.data_ptr(), Co, out.data_ptr(), Co, N, hw, Co, gbt.data_ptr(), 2 * Co,
+                                     part2.data_ptr(), code, K._stream(xt)) == 0
+        assert torch.equal(part, part2)
+        assert torch.equal(a, ref)
+        y = O.conv2d(xt.float().cpu().permute(0, 3, 1, 2).numpy(), wp_ref(w, dtype), b, 1, 1, 1)
+        y = np.where(y > 0, y, 0.2 * y) * 0.7 + 0.7 * rt.float().cpu().permute(0, 3, 1, 2).numpy()
+        assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), y) < (F32_TOL if dtype == torch.float32 else 2e-2)
+
+
+def wp_ref(w, dtype):
+    return w if dtype == torch.float32 else torch.from_numpy(w).to(torch.bfloat16).float().numpy()
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--nosplit", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the register-staged loader")
     ap.add_argument("--nopatch", action="store_true", help="disable the patch-resident kernel")
+    ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
     args = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
@@ -89,6 +90,12 @@ def main():
         d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout,
                              kh=k, kw=k, stride=stride, pad=pad, dil=dil, phases=phases, bias=bias,
                              act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint + (1000000000 if args.generic else 0) + (200000000 if args.nopatch else 0), **kw)
+        if args.rgb and name.startswith("same") and lay == "nhwc" and cout <= 128:
+            rgbw = (torch.randn(3, 1, cout, device=dev) / cout ** 0.5).to(dt)
+            rgbb = torch.randn(3, device=dev)
+            rgbo = torch.randn(n, 3, ho, wo, device=dev)
+            d.rgb_weight, d.rgb_bias = rgbw.data_ptr(), rgbb.data_ptr()
+            d.rgb_resid = d.rgb_out = rgbo.data_ptr()
         if not args.nosplit:
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         tile = lib.vt_conv2d_tile(C.byref(d))

@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ("slope_vec", C.c_void_p),
         ("rgb_weight", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_resid", C.c_void_p), ("rgb_out", C.c_void_p),
         ("splitk_phase", C.c_int32),
+        ("stats_part", C.c_void_p),
     ]
 
 
@@ -91,6 +92,8 @@ _SIGS = {
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p]),
     "vt_instnorm_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vt_instnorm_apply_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vt_affine_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

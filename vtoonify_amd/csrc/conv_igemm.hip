@@ -72,6 +72,8 @@ struct ConvArgs {
     int* tickets;       // per-tile arrival counters (zero between launches) or NULL = two-pass split-K
     int phase;          // 0 = slices + reduce, 1 = slices only, 2 = reduce only (two-pass split-K)
     int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
+    StatRec* stats_part;  // InstanceNorm chunk records of the output (vt_conv_desc.stats_part) or NULL
+    int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
 template <typename T>
@@ -1066,6 +1068,24 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         }
     };
 
+    // fused-ToRGB constants in registers for the life of the workgroup
+    const bool rgbf = p.rgb_w != nullptr;
+    float rwt[3][TN][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rwt[j][b][i] = rgbf ? to_f32(((const T*)p.rgb_w)[j * 32 + b * 16 + q * 4 + i]) : 0.0f;
+    float bvr[TN][4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias ? p.bias[b * 16 + q * 4 + i] : 0.0f;
+    const float rb0 = (rgbf && p.rgb_bias) ? p.rgb_bias[0] : 0.0f, rb1 = (rgbf && p.rgb_bias) ? p.rgb_bias[1] : 0.0f,
+                rb2 = (rgbf && p.rgb_bias) ? p.rgb_bias[2] : 0.0f;
+
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     issue(tile, 0);
@@ -1079,6 +1099,27 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             vt_glds_wait_n<0>();
         }
         vt_lds_barrier();
+        const int img = tile / (tiles_x * tiles_y);
+        const int trem = tile - img * (tiles_x * tiles_y);
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const PatchRows<TW> rowmap{img, y0, x0, p.Ho, p.Wo};
+        const int HoWo = p.Ho * p.Wo;
+        // the up-sampled skip this tile adds to: fetched NOW so the loads fly during the 9 taps
+        float rsd[TM][3];
+        if (rgbf && p.rgb_resid && q == 0 && p.dbg != 2) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+                const int mm = m < 0 ? 0 : m;
+                const int im = mm / HoWo;
+                const int64_t o0 = (int64_t)im * 3 * HoWo + (mm - im * HoWo);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rsd[a][j] = p.rgb_resid[o0 + (int64_t)j * HoWo];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) rsd[a][0] = rsd[a][1] = rsd[a][2] = 0.0f;
+        }
         f32x4 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -1101,16 +1142,10 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             vt_sched_fence();   // keep one tap's fragments live at a time (the scheduler otherwise
                                 // hoists all 36 reads: 376 registers, occupancy 1)
         }
-        const int img = tile / (tiles_x * tiles_y);
-        const int trem = tile - img * (tiles_x * tiles_y);
-        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         // lean epilogue (the generic one costs ~200 registers next to the resident weights):
         // bias + LeakyReLU * gain -> bf16 NHWC (8-byte stores), optional fused ToRGB
         {
-            const PatchRows<TW> rowmap{img, y0, x0, p.Ho, p.Wo};
             const float ga = p.gain_alpha;
-            const bool rgbf = p.rgb_w != nullptr;
-            const int HoWo = p.Ho * p.Wo;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
@@ -1121,17 +1156,16 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                     float f[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = acc[a][b][i] + (p.bias ? p.bias[n + i] : 0.0f);
+                        float v = acc[a][b][i] + bvr[b][i];
                         if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
                         f[i] = v * ga;
                     }
                     if (rgbf) {
-                        const T* rw = (const T*)p.rgb_w + n;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            r0 += f[i] * to_f32(rw[i]);
-                            r1 += f[i] * to_f32(rw[32 + i]);
-                            r2 += f[i] * to_f32(rw[64 + i]);
+                            r0 += f[i] * rwt[0][b][i];
+                            r1 += f[i] * rwt[1][b][i];
+                            r2 += f[i] * rwt[2][b][i];
                         }
                     }
                     if (m >= 0) {
@@ -1142,20 +1176,17 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                     }
                 }
                 if (rgbf) {
+                    if (p.dbg != 3) {
                     r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
                     r1 += __shfl_xor(r1, 16, 64); r1 += __shfl_xor(r1, 32, 64);
                     r2 += __shfl_xor(r2, 16, 64); r2 += __shfl_xor(r2, 32, 64);
-                    if (q == 0 && m >= 0) {
+                    }
+                    if (q == 0 && m >= 0 && (p.dbg != 1 || r0 == 123.456f)) {
                         const int im = m / HoWo;
                         const int64_t o0 = (int64_t)im * 3 * HoWo + (m - im * HoWo);
-                        const float rr[3] = {r0, r1, r2};
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const int64_t off = o0 + (int64_t)j * HoWo;
-                            float v = rr[j] + (p.rgb_bias ? p.rgb_bias[j] : 0.0f);
-                            if (p.rgb_resid) v += p.rgb_resid[off];
-                            p.rgb_out[off] = v;
-                        }
+                        p.rgb_out[o0] = r0 + rb0 + rsd[a][0];
+                        p.rgb_out[o0 + HoWo] = r1 + rb1 + rsd[a][1];
+                        p.rgb_out[o0 + 2 * (int64_t)HoWo] = r2 + rb2 + rsd[a][2];
                     }
                 }
             }
@@ -1216,6 +1247,144 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
             }
         }
     }
+}
+
+// Split-K reduce pass that ALSO emits the InstanceNorm chunk records of the tensor it writes (the
+// 32x32-pixel trunk: every conv feeds an AdaIN, and a separate statistics launch re-reads 1 MB for
+// 5 us of launch latency).  Same work split as instnorm_partial_kernel -- one workgroup per
+// (image, chunk of pixels), all channels, threads = channel vectors x pixel rows, identical
+// accumulation order on the ROUNDED values that are stored -- so the records are bit-identical to
+// what the stand-alone statistics pass would produce from the stored tensor.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int UNR = 4;
+    __shared__ float red[256 * VEC * 2];
+    const int tid = threadIdx.x;
+    const int hw = p.Ho * p.Wo;
+    const int chunk = blockIdx.x % chunks, img = blockIdx.x / chunks;
+    const int p_lo = chunk * chunk_px;
+    const int p_hi = (p_lo + chunk_px < hw) ? p_lo + chunk_px : hw;
+    const int c = p.coutT;
+    const int cvn = c / VEC;
+    const int cpar = cvn < 256 ? cvn : 256;
+    const int rows = 256 / cpar;
+    const int cv0 = tid % cpar, prow = tid / cpar;
+    const bool active = prow < rows;
+    const int64_t slab = (int64_t)p.M * p.ldp;
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+
+    // finished, ROUNDED output vector (pixel px, channel vector cv); optionally stored
+    auto finish = [&](int px, int cv, float* f, bool store) {
+        const int64_t m = (int64_t)img * hw + px;
+        const int n = cv * VEC;
+        const float* src = p.partial + m * p.ldp + n;
+#pragma unroll
+        for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + v), f + v);
+        for (int s = 1; s < p.splitk; ++s) {
+            float g[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + s * slab + v), g + v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] += g[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int nn = n + i;
+            const float bv = p.bias ? p.bias[nn] : 0.0f;
+            f[i] = conv_finish(p, f[i], bv, ga, p.slope_vec ? p.slope_vec[nn] : p.slope);
+        }
+        if (p.resid) {
+            float g[VEC];
+            unpack16<T>(ld128((const T*)p.resid + m * p.ld_res + n), g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) f[i] += p.beta * g[i];
+        }
+        const u128 packed = pack16<T>(f);
+        if (store) st128((T*)p.out + m * p.ld_out + n, packed);
+        unpack16<T>(packed, f);
+    };
+
+    for (int cbase = 0; cbase < cvn; cbase += cpar) {
+        const int cv = cbase + cv0;
+        const bool on = active && cv < cvn;
+        float x0[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) x0[i] = s1[i] = s2[i] = 0.0f;
+        if (on) {
+            finish(p_lo, cv, x0, false);   // shift = the chunk's first pixel
+            for (int px = p_lo + prow; px < p_hi; px += rows * UNR) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = px + u * rows;
+                    if (q < p_hi) {
+                        float f[VEC];
+                        finish(q, cv, f, true);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const float d = f[i] - x0[i];
+                            s1[i] += d;
+                            s2[i] += d * d;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[(tid * VEC + i) * 2 + 0] = s1[i];
+            red[(tid * VEC + i) * 2 + 1] = s2[i];
+        }
+        __syncthreads();
+        if (on && prow == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float a1 = 0.0f, a2 = 0.0f;
+                for (int r = 0; r < rows; ++r) {
+                    const int t = r * cpar + cv0;
+                    a1 += red[(t * VEC + i) * 2 + 0];
+                    a2 += red[(t * VEC + i) * 2 + 1];
+                }
+                StatRec rec;
+                rec.x0 = x0[i];
+                rec.s1 = a1;
+                rec.s2 = a2;
+                p.stats_part[((int64_t)img * chunks + chunk) * c + cv * VEC + i] = rec;
+            }
+        }
+    }
+}
+
+// set by launch_reduce when the reduce pass wrote the chunk records (vt_conv2d then skips the
+// stand-alone statistics launch)
+static thread_local bool g_stats_emitted = false;
+
+// the tensor this conv writes can carry InstanceNorm records: NHWC, compute dtype, vector stores
+static bool stats_fusable(const ConvArgs& a, int esz) {
+    const int vec = 16 / esz;
+    return a.stats_part && a.out_layout == VT_OUT_NHWC && a.phases == 1 && a.vec_store &&
+           a.out_f32 == (esz == 4) && a.coutT % vec == 0 && a.ld_out % vec == 0 && a.ldp % vec == 0 &&
+           (!a.resid || a.ld_res % vec == 0);
+}
+
+// second pass of the two-pass split-K
+template <typename T>
+static int launch_reduce(const ConvArgs& args, vt_stream stream) {
+    if (stats_fusable(args, (int)sizeof(T))) {
+        const int hw = args.Ho * args.Wo;
+        const int cpx = stat_chunk_pixels(hw);
+        const int chunks = (hw + cpx - 1) / cpx;
+        auto k = conv_splitk_reduce_stats_kernel<T>;
+        VT_LAUNCH(k, dim3((unsigned)(args.N * chunks)), dim3(256), stream, args, cpx, chunks);
+        g_stats_emitted = true;
+        return vt_check_launch("vt_conv2d(split-K reduce + statistics)");
+    }
+    int64_t blocks = ((int64_t)args.M * (args.ldp / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), stream, args);
+    return vt_check_launch("vt_conv2d(split-K reduce)");
 }
 
 // The direct-to-LDS loader applies when every K-step stays inside one tap and one source and
@@ -1310,10 +1479,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     }
     int rc = vt_check_launch("vt_conv2d");
     if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
-    int64_t blocks = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), stream, args);
-    return vt_check_launch("vt_conv2d(split-K reduce)");
+    return launch_reduce<T>(args, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1498,10 +1664,7 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     }
     int rc = vt_check_launch("vt_conv2d(patch)");
     if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
-    int64_t rb = ((int64_t)a.M * (args.ldp / 8) + 255) / 256;
-    if (rb > 4096) rb = 4096;
-    VT_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), stream, args);
-    return vt_check_launch("vt_conv2d(split-K reduce)");
+    return launch_reduce<T>(args, stream);
 }
 
 template <typename T>
@@ -1611,6 +1774,9 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
                    (int64_t)d->n * d->out_h * d->out_w * (d->phases == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "vt_conv2d: tensor too large for 32-bit pixel indices");
 
+    VT_REQUIRE(!d->stats_part || (d->phases == 1 && d->out_layout == VT_OUT_NHWC && d->out_dtype == d->dtype &&
+                                  d->cout % 8 == 0 && (d->dtype == VT_BF16 || d->dtype == VT_F32)),
+               "vt_conv2d: stats_part needs phases == 1, NHWC output in the compute dtype, cout %% 8 == 0");
     VT_REQUIRE(!d->rgb_weight || (d->rgb_out && d->phases == 1 && d->out_layout == VT_OUT_NHWC && !d->transposed),
                "vt_conv2d: fused ToRGB needs rgb_out, phases == 1 and NHWC output");
     memset(&a, 0, sizeof(a));
@@ -1623,6 +1789,11 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.rgb_bias = d->rgb_bias;
     a.rgb_resid = d->rgb_resid;
     a.rgb_out = d->rgb_out;
+    a.stats_part = (StatRec*)d->stats_part;
+    {
+        const char* e = getenv("VT_RGB_ABLATE");
+        a.dbg = e ? atoi(e) : 0;
+    }
     a.alpha_dev = d->alpha_dev;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;
@@ -1674,8 +1845,13 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
     const int rc = fill_args(d, a);
     if (rc != VT_OK) return rc;
     const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
-    if (d->dtype == VT_BF16) return dispatch<bf16_t>(a, d->tile_hint, wsf, stream);
-    return dispatch<float>(a, d->tile_hint, wsf, stream);
+    g_stats_emitted = false;
+    const int rcl = d->dtype == VT_BF16 ? dispatch<bf16_t>(a, d->tile_hint, wsf, stream)
+                                        : dispatch<float>(a, d->tile_hint, wsf, stream);
+    if (rcl != VT_OK || !a.stats_part || g_stats_emitted || d->splitk_phase == 1) return rcl;
+    // the plan had no reduce pass to carry the statistics: append the stand-alone launch
+    return vt_internal_instnorm_partial(a.stats_part, d->out, d->ld_out, d->n, d->out_h * d->out_w, d->cout,
+                                        d->dtype, stream);
 }
 
 extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {

@@ -16,21 +16,6 @@ namespace {
 
 constexpr float IN_EPS = 1e-5f;  // nn.InstanceNorm2d default (dualstylegan.py:10)
 
-struct StatRec {
-    float x0, s1, s2;
-};
-
-// chunk geometry shared by host and device.  It depends on the plane size ONLY (never on the
-// batch), so a frame's statistics -- hence its output bits -- are the same whether it is
-// processed alone or inside a batch.
-__host__ __device__ inline int stat_chunk_pixels(int hw) {
-    // ~256 chunks per image, 16..4096 pixels each
-    int px = (hw + 255) / 256;
-    if (px < 16) px = 16;
-    if (px > 4096) px = 4096;
-    return px;
-}
-
 // One workgroup reduces a chunk of pixels for ALL channels in a single pass: x (and `other`) are
 // read once, the statistics of x and of |x - other| are accumulated together, and 4 pixels per
 // thread are in flight (independent 16-byte loads, accumulated in pixel order).
@@ -675,6 +660,48 @@ extern "C" int vt_upsample_bilinear_add(void* out, const void* x, const void* y,
         return VT_ERR_UNSUPPORTED;
     }
     return vt_check_launch("vt_upsample_bilinear_add");
+}
+
+int vt_internal_instnorm_partial(void* partials, const void* x, int ld_x, int n, int hw, int c, int dtype,
+                                 vt_stream stream) {
+    const int cpx = stat_chunk_pixels(hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    dim3 grid((unsigned)(n * chunks)), block(256);
+    if (dtype == VT_F32) {
+        auto k = instnorm_partial_kernel<float, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const float*)x, ld_x, (const float*)nullptr, 0, hw, c, cpx, chunks);
+    } else {
+        auto k = instnorm_partial_kernel<bf16_t, false>;
+        VT_LAUNCH(k, grid, block, stream, (StatRec*)partials, (const bf16_t*)x, ld_x, (const bf16_t*)nullptr, 0, hw, c, cpx, chunks);
+    }
+    return vt_check_launch("instnorm statistics");
+}
+
+// The finalize/apply half of vt_instnorm_apply alone: `partials` already hold the chunk records of
+// x -- written by the conv that produced x (vt_conv_desc.stats_part).
+extern "C" int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
+                                       const float* style_gb, int ld_gb, const void* partials, int dtype,
+                                       vt_stream stream) {
+    VT_REQUIRE(out && x && partials, "vt_instnorm_apply_stats: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 16 == 0, "vt_instnorm_apply_stats: c must be a positive multiple of 16");
+    VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_apply_stats: dtype");
+    if ((int64_t)hw > 16384) {
+        vt_set_error("vt_instnorm_apply_stats: tensor too large for the fused form");
+        return VT_ERR_UNSUPPORTED;
+    }
+    const int cpx = stat_chunk_pixels(hw);
+    const int chunks = (hw + cpx - 1) / cpx;
+    const unsigned nblk = (unsigned)(n * (c / (dtype == VT_F32 ? 4 : 8)));
+    if (dtype == VT_F32) {
+        auto k = instnorm_apply_small_kernel<float>;
+        VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (float*)out, ld_out, (const float*)x, ld_x,
+                  (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb);
+    } else {
+        auto k = instnorm_apply_small_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (bf16_t*)out, ld_out, (const bf16_t*)x, ld_x,
+                  (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb);
+    }
+    return vt_check_launch("vt_instnorm_apply_stats");
 }
 
 // AdaIN in two launches (statistics + fused finalize/apply) when the tensor is small enough for

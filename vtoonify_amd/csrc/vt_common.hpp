@@ -280,3 +280,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int vt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- InstanceNorm chunk records, shared by norm_glue.hip and the conv kernels that emit them ----
+struct StatRec {
+    float x0, s1, s2;   // shift (the chunk's first pixel), sum(x-x0), sum((x-x0)^2)
+};
+// chunk geometry shared by host and device.  It depends on the plane size ONLY (never on the
+// batch), so a frame's statistics -- hence its output bits -- are the same whether it is
+// processed alone or inside a batch.
+__host__ __device__ inline int stat_chunk_pixels(int hw) {
+    // ~256 chunks per image, 16..4096 pixels each
+    int px = (hw + 255) / 256;
+    if (px < 16) px = 16;
+    if (px > 4096) px = 4096;
+    return px;
+}
+// statistics pass alone (norm_glue.hip); library-internal
+__attribute__((visibility("hidden"))) int vt_internal_instnorm_partial(void* partials, const void* x, int ld_x,
+                                                                       int n, int hw, int c, int dtype,
+                                                                       vt_stream stream);

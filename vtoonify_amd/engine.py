@@ -350,7 +350,8 @@ class VToonifyEngine:
             self._op_conv(ops, plan, src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                           weight=self.w[f"{rk}.{ii}.conv2"], cout=cf, kh=3, kw=3, pad=1,
                           bias=sd[f"{rk}.{ii}.conv2.bias"], act=ACT_LRELU, alpha=1 / SQRT2, beta=1 / SQRT2,
-                          resid=feat, ld_res=cf, out=nxt, ld_out=cf)
+                          resid=feat, ld_res=cf, out=nxt, ld_out=cf,
+                          stats_part=ws if (self.dual and has_res and hw <= 16384) else None)
             feat = nxt
             if self.dual and has_res:
                 r = ii + 1
@@ -361,13 +362,14 @@ class VToonifyEngine:
                     # AdaIN as statistics + one fused finalize/apply launch (small tensor), written to
                     # its own buffer so that the conv runs the direct-to-LDS loader; the in-loader
                     # affine (in_scale/in_shift of vt_conv2d) costs more in the MFMA loop than this
-                    if hw <= 16384:   # vt_instnorm_apply: fused finalize+apply for small planes
-                        ops.append((lib.vt_instnorm_apply,
+                    if hw <= 16384:   # fused finalize+apply for small planes; the chunk records come
+                        # from the conv that produced `src` (its split-K reduce pass emits them)
+                        ops.append((lib.vt_instnorm_apply_stats,
                                     (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
                                      C.c_void_p(gb.data_ptr()), 0 if ns == 1 else gb.shape[1],
                                      C.c_void_p(ws.data_ptr()), dt),
                                     {"name": "adain", "kernel": "instnorm_apply", "flops": 0,
-                                     "bytes": 3 * B * hw * cf * self.esz}))
+                                     "bytes": 2 * B * hw * cf * self.esz}))
                     else:   # large planes: separate finalize (parallel tree merge) and apply
                         ops.append((lib.vt_instnorm_stats,
                                     (C.c_void_p(sc1.data_ptr()), C.c_void_p(sh1.data_ptr()), C.c_void_p(src.data_ptr()),
@@ -386,7 +388,8 @@ class VToonifyEngine:
                         self._op_conv(ops, plan, src0=nrm_res, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                                       weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
                                       bias=sd[f"res.{r}.{cn}.1.bias"],
-                                      act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf)
+                                      act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf,
+                                      stats_part=ws if hw <= 16384 else None)
                     else:
                         nxt = ping[pp]; pp ^= 1
                         # out * d_s + skip  (d_s read from device memory: graph-replay safe)
@@ -537,7 +540,8 @@ class VToonifyEngine:
                 plan.keep.append(d2)
                 m, cout_t = info["m"], info["cout"]
                 osz = 4 if d.out_dtype == K.VT_F32 else 2
-                rinfo = {"name": "splitk_reduce", "kernel": "conv_splitk_reduce_kernel", "flops": 0,
+                rk = "conv_splitk_reduce_stats_kernel" if d.stats_part else "conv_splitk_reduce_kernel"
+                rinfo = {"name": "splitk_reduce", "kernel": rk, "flops": 0,
                          "bytes": sk * m * ((cout_t + 7) // 8 * 8) * 4 + m * cout_t * osz}
                 inserts.append((ops, pos, (self.lib.vt_conv2d, (C.byref(d2),), rinfo)))
         # insert the reduce ops right after their slice ops (back to front keeps positions valid)
