@@ -1250,110 +1250,101 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
 }
 
 // Split-K reduce pass that ALSO emits the InstanceNorm chunk records of the tensor it writes (the
-// 32x32-pixel trunk: every conv feeds an AdaIN, and a separate statistics launch re-reads 1 MB for
-// 5 us of launch latency).  Same work split as instnorm_partial_kernel -- one workgroup per
-// (image, chunk of pixels), all channels, threads = channel vectors x pixel rows, identical
-// accumulation order on the ROUNDED values that are stored -- so the records are bit-identical to
-// what the stand-alone statistics pass would produce from the stored tensor.
+// 32x32-pixel trunk: every conv feeds an AdaIN, and a separate statistics launch re-reads the tensor
+// for 5 us of latency).  One workgroup per (image, statistics chunk, group of CG channel vectors):
+// threads = CG channel vectors x 256/CG pixel rows, so at the trunk's 16-pixel chunks every thread
+// owns ONE pixel and fetches its S slab vectors + the residual in a single round trip.  The
+// finished, ROUNDED vectors go to the output and to LDS; one thread per channel then folds the
+// chunk in exactly the order instnorm_partial_kernel uses (pixel rows r = 0..rowsP-1, each row's
+// pixels in order, rows summed in order) -- the records are bit-identical to what the stand-alone
+// statistics pass produces from the stored tensor.  chunk_px <= 64 (planes up to 16384 pixels).
 template <typename T>
 __global__ void __launch_bounds__(256)
-conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks) {
+conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks, int cgroups) {
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int UNR = 4;
-    __shared__ float red[256 * VEC * 2];
+    constexpr int CG = 16;            // channel vectors per workgroup
+    constexpr int ROWS = 256 / CG;    // pixel rows per workgroup
+    constexpr int SG = 8;             // slabs fetched per round trip
+    constexpr int MAXPX = 64;
+    __shared__ float vals[MAXPX][CG * VEC + 1];
     const int tid = threadIdx.x;
     const int hw = p.Ho * p.Wo;
-    const int chunk = blockIdx.x % chunks, img = blockIdx.x / chunks;
+    const int cg = blockIdx.x % cgroups;
+    const int chunk = (blockIdx.x / cgroups) % chunks, img = blockIdx.x / (cgroups * chunks);
     const int p_lo = chunk * chunk_px;
     const int p_hi = (p_lo + chunk_px < hw) ? p_lo + chunk_px : hw;
     const int c = p.coutT;
     const int cvn = c / VEC;
-    const int cpar = cvn < 256 ? cvn : 256;
-    const int rows = 256 / cpar;
-    const int cv0 = tid % cpar, prow = tid / cpar;
-    const bool active = prow < rows;
+    const int cvl = tid % CG, prow = tid / CG;
+    const int cv = cg * CG + cvl;
+    const int n = cv * VEC;
     const int64_t slab = (int64_t)p.M * p.ldp;
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
-
-    // finished, ROUNDED output vector (pixel px, channel vector cv); optionally stored
-    auto finish = [&](int px, int cv, float* f, bool store) {
-        const int64_t m = (int64_t)img * hw + px;
-        const int n = cv * VEC;
-        const float* src = p.partial + m * p.ldp + n;
-#pragma unroll
-        for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + v), f + v);
-        for (int s = 1; s < p.splitk; ++s) {
-            float g[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + s * slab + v), g + v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) f[i] += g[i];
-        }
+    if (cv < cvn) {
+        float bv[VEC], sv[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const int nn = n + i;
-            const float bv = p.bias ? p.bias[nn] : 0.0f;
-            f[i] = conv_finish(p, f[i], bv, ga, p.slope_vec ? p.slope_vec[nn] : p.slope);
+            bv[i] = p.bias ? p.bias[n + i] : 0.0f;
+            sv[i] = p.slope_vec ? p.slope_vec[n + i] : p.slope;
         }
-        if (p.resid) {
-            float g[VEC];
-            unpack16<T>(ld128((const T*)p.resid + m * p.ld_res + n), g);
+        for (int px = p_lo + prow; px < p_hi; px += ROWS) {
+            const int64_t m = (int64_t)img * hw + px;
+            const float* src = p.partial + m * p.ldp + n;
+            float f[VEC], r[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) f[i] += p.beta * g[i];
-        }
-        const u128 packed = pack16<T>(f);
-        if (store) st128((T*)p.out + m * p.ld_out + n, packed);
-        unpack16<T>(packed, f);
-    };
-
-    for (int cbase = 0; cbase < cvn; cbase += cpar) {
-        const int cv = cbase + cv0;
-        const bool on = active && cv < cvn;
-        float x0[VEC], s1[VEC], s2[VEC];
+            for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + v), f + v);
+            if (p.resid) unpack16<T>(ld128((const T*)p.resid + m * p.ld_res + n), r);
+            for (int s0 = 1; s0 < p.splitk; s0 += SG) {   // slice order 0..S-1: deterministic
+                float g[SG][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) x0[i] = s1[i] = s2[i] = 0.0f;
-        if (on) {
-            finish(p_lo, cv, x0, false);   // shift = the chunk's first pixel
-            for (int px = p_lo + prow; px < p_hi; px += rows * UNR) {
+                for (int k = 0; k < SG; ++k) {
+                    const int s = (s0 + k < p.splitk) ? s0 + k : 0;   // clamped: loads stay unconditional
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int q = px + u * rows;
-                    if (q < p_hi) {
-                        float f[VEC];
-                        finish(q, cv, f, true);
+                    for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + s * slab + v), g[k] + v);
+                }
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            const float d = f[i] - x0[i];
-                            s1[i] += d;
-                            s2[i] += d * d;
-                        }
+                for (int k = 0; k < SG; ++k) {
+                    if (s0 + k < p.splitk) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) f[i] += g[k][i];
                     }
                 }
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            red[(tid * VEC + i) * 2 + 0] = s1[i];
-            red[(tid * VEC + i) * 2 + 1] = s2[i];
-        }
-        __syncthreads();
-        if (on && prow == 0) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                float a1 = 0.0f, a2 = 0.0f;
-                for (int r = 0; r < rows; ++r) {
-                    const int t = r * cpar + cv0;
-                    a1 += red[(t * VEC + i) * 2 + 0];
-                    a2 += red[(t * VEC + i) * 2 + 1];
-                }
-                StatRec rec;
-                rec.x0 = x0[i];
-                rec.s1 = a1;
-                rec.s2 = a2;
-                p.stats_part[((int64_t)img * chunks + chunk) * c + cv * VEC + i] = rec;
+                f[i] = conv_finish(p, f[i], bv[i], ga, sv[i]);
+                if (p.resid) f[i] += p.beta * r[i];
             }
+            const u128 packed = pack16<T>(f);
+            st128((T*)p.out + m * p.ld_out + n, packed);
+            unpack16<T>(packed, f);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) vals[px - p_lo][cvl * VEC + i] = f[i];
         }
+    }
+    __syncthreads();
+    // fold: thread t owns channel cg*CG*VEC + t of this chunk
+    const int ch = cg * CG * VEC + tid;
+    if (tid < CG * VEC && ch < c) {
+        const int cparP = cvn < 256 ? cvn : 256;
+        const int rowsP = 256 / cparP;            // instnorm_partial_kernel's pixel rows
+        const float x0 = vals[0][tid];
+        float a1 = 0.0f, a2 = 0.0f;
+        for (int r = 0; r < rowsP; ++r) {
+            float t1 = 0.0f, t2 = 0.0f;
+            for (int px = p_lo + r; px < p_hi; px += rowsP) {
+                const float d = vals[px - p_lo][tid] - x0;
+                t1 += d;
+                t2 += d * d;
+            }
+            a1 += t1;
+            a2 += t2;
+        }
+        StatRec rec;
+        rec.x0 = x0;
+        rec.s1 = a1;
+        rec.s2 = a2;
+        p.stats_part[((int64_t)img * chunks + chunk) * c + ch] = rec;
     }
 }
 
@@ -1366,7 +1357,7 @@ static bool stats_fusable(const ConvArgs& a, int esz) {
     const int vec = 16 / esz;
     return a.stats_part && a.out_layout == VT_OUT_NHWC && a.phases == 1 && a.vec_store &&
            a.out_f32 == (esz == 4) && a.coutT % vec == 0 && a.ld_out % vec == 0 && a.ldp % vec == 0 &&
-           (!a.resid || a.ld_res % vec == 0);
+           (!a.resid || a.ld_res % vec == 0) && stat_chunk_pixels(a.Ho * a.Wo) <= 64;
 }
 
 // second pass of the two-pass split-K
@@ -1376,8 +1367,9 @@ static int launch_reduce(const ConvArgs& args, vt_stream stream) {
         const int hw = args.Ho * args.Wo;
         const int cpx = stat_chunk_pixels(hw);
         const int chunks = (hw + cpx - 1) / cpx;
+        const int cgroups = vt_cdiv(args.coutT / (16 / (int)sizeof(T)), 16);
         auto k = conv_splitk_reduce_stats_kernel<T>;
-        VT_LAUNCH(k, dim3((unsigned)(args.N * chunks)), dim3(256), stream, args, cpx, chunks);
+        VT_LAUNCH(k, dim3((unsigned)(args.N * chunks * cgroups)), dim3(256), stream, args, cpx, chunks, cgroups);
         g_stats_emitted = true;
         return vt_check_launch("vt_conv2d(split-K reduce + statistics)");
     }

@@ -342,6 +342,7 @@ class VToonifyEngine:
         feat = cur
         pp = 0
         rk = f"encoder.{self.n_down}"
+        fuse_stats = os.environ.get("VT_FUSE_STATS", "1") != "0"   # A/B switch
         for ii in range(6):
             self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                           weight=self.w[f"{rk}.{ii}.conv"], cout=cf, kh=3, kw=3, pad=1,
@@ -351,7 +352,7 @@ class VToonifyEngine:
                           weight=self.w[f"{rk}.{ii}.conv2"], cout=cf, kh=3, kw=3, pad=1,
                           bias=sd[f"{rk}.{ii}.conv2.bias"], act=ACT_LRELU, alpha=1 / SQRT2, beta=1 / SQRT2,
                           resid=feat, ld_res=cf, out=nxt, ld_out=cf,
-                          stats_part=ws if (self.dual and has_res and hw <= 16384) else None)
+                          stats_part=ws if (self.dual and has_res and hw <= 16384 and fuse_stats) else None)
             feat = nxt
             if self.dual and has_res:
                 r = ii + 1
@@ -364,7 +365,7 @@ class VToonifyEngine:
                     # affine (in_scale/in_shift of vt_conv2d) costs more in the MFMA loop than this
                     if hw <= 16384:   # fused finalize+apply for small planes; the chunk records come
                         # from the conv that produced `src` (its split-K reduce pass emits them)
-                        ops.append((lib.vt_instnorm_apply_stats,
+                        ops.append((lib.vt_instnorm_apply_stats if fuse_stats else lib.vt_instnorm_apply,
                                     (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
                                      C.c_void_p(gb.data_ptr()), 0 if ns == 1 else gb.shape[1],
                                      C.c_void_p(ws.data_ptr()), dt),
@@ -389,7 +390,7 @@ class VToonifyEngine:
                                       weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
                                       bias=sd[f"res.{r}.{cn}.1.bias"],
                                       act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf,
-                                      stats_part=ws if hw <= 16384 else None)
+                                      stats_part=ws if (hw <= 16384 and fuse_stats) else None)
                     else:
                         nxt = ping[pp]; pp ^= 1
                         # out * d_s + skip  (d_s read from device memory: graph-replay safe)
