@@ -78,6 +78,26 @@ def pmc_traffic(kernel_class: str):
     return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hit) / n
 
 
+def video_rate(eng, style, d_s, H, W, batch, use_graph, n_frames=96):
+    """End-to-end frames/s of vtoonify_amd.video.VideoToonifier: host uint8 frames (+ fp32 parsing
+    maps) -> H2D -> pack -> forward -> unpack -> D2H -> sink, double-buffered.  Synthetic frames."""
+    import numpy as np
+    from vtoonify_amd import video
+    g = np.random.default_rng(0)
+    frames = g.integers(0, 256, (8, H, W, 3), dtype=np.uint8)
+    parsing = (g.standard_normal((8, 19, H, W)) * 4).astype(np.float32)
+    vt = video.VideoToonifier(eng, style, d_s, batch_size=batch, bgr=True, depth=2, use_graph=use_graph)
+    sink = lambda i, fr: None
+    vt.run(((frames[i % 8], parsing[i % 8]) for i in range(2 * batch)), sink)   # warm-up (plans, graph, pinned buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vt.run(((frames[i % 8], parsing[i % 8]) for i in range(n_frames)), sink)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "batch": batch,
+            "what": "host uint8 BGR frames + fp32 parsing maps in, uint8 BGR frames out (pinned, 2 batches in flight)"}
+
+
 def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
     """Time the CPU oracle on the host cores.  Sample: ONE frame of the benchmark workload when
     that fits the budget, otherwise a centre crop scaled to it (cost is linear in H*W)."""
@@ -130,6 +150,7 @@ def main():
     ap.add_argument("--d-s", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-video", action="store_true", help="skip the PCIe-inclusive video-driver measurement")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
     ap.add_argument("--op-iters", type=int, default=5, help="instrumented frames for per-kernel timing")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table (stderr)")
@@ -258,6 +279,11 @@ def main():
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                         for r in rows[:8]],
         }
+    # PCIe-inclusive rate of the same workload through the video driver (uint8 frames + parsing maps
+    # in host memory -> uint8 frames in host memory; vtoonify_amd/video.py).  Reported beside `value`,
+    # never as `value` (inputs of the timed region above are resident in HBM).
+    if rank == 0 and ws == 1 and not args.no_video:
+        result["pcie_inclusive"] = video_rate(eng, style, d_s, H, W, max(B, 4), use_graph)
     # the CPU baseline runs after the GPU numbers are final (rank 0, single-GPU runs only)
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         del eng, sd_dev

@@ -250,6 +250,23 @@ int vt_fusion_pack(void* out, int ld_out, const void* f_e, int ld_e, const float
                    const float* skip, int n, int hw, int c, int dtype, vt_stream stream);
 
 /* ---------------------------------------------------------------------------------
+ * Frame packing either side of VToonify.forward: the per-frame host work of the reference's
+ * video loop (style_transfer.py:99-183) as two streaming kernels.
+ *   vt_frame_pack    frames (n,h,w,3) uint8 [+ parsing (n,pc,h,w) fp32] -> x (n,3+pc,h,w) fp32:
+ *                    x[c] = ((u8/255) - 0.5) / 0.5  (transforms.ToTensor + Normalize(0.5,0.5),
+ *                    style_transfer.py:57-60,160), x[3+j] = parsing[j] * parsing_scale (x_p/16.,
+ *                    style_transfer.py:174).  swap_rb != 0: frames are BGR as cv2 delivers them
+ *                    (replaces cv2.cvtColor(frame, COLOR_BGR2RGB), style_transfer.py:114).
+ *   vt_frame_unpack  image (n,3,H,W) fp32 -> frames (n,H,W,3) uint8:
+ *                    u8 = (uint8)((clamp(y,-1,1) + 1.0) * 127.5)  (style_transfer.py:177 +
+ *                    tensor2cv2, util.py:190-192); swap_rb != 0 writes BGR (tensor2cv2's cvtColor).
+ * fp32 op order is the reference's; results are bit-exact against the numpy/torch formulas.
+ * --------------------------------------------------------------------------------- */
+int vt_frame_pack(float* x, const uint8_t* frames, int swap_rb, const float* parsing, int parsing_channels,
+                  float parsing_scale, int n, int h, int w, vt_stream stream);
+int vt_frame_unpack(uint8_t* frames, const float* image, int swap_rb, int n, int h, int w, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
  * pSp style-encoder glue (GradualStyleEncoder, model/encoder/encoders/psp_encoders.py:35-116,
  * bottleneck_IR_SE / SEModule, helpers.py:53-119), NHWC activations.
  *   vt_channel_mean           AdaptiveAvgPool2d(1): mean[n][c] fp32 (deterministic two-stage
