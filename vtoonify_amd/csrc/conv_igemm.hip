@@ -282,6 +282,52 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
     }
 }
 
+// Fragment order of the output channels.  With the weights as the MFMA "A" operand, lane group q
+// of fragment b holds rows 4q..4q+3 of that fragment.  When a wave owns an even number of
+// fragments, the weight rows are loaded into the LDS tile in the order
+//     tile row 32j + 16h + 4q + r   <-   channel 32j + 8q + 4h + r        (h = fragment parity)
+// so that lane group q holds EIGHT consecutive channels across the fragment pair (2j, 2j+1): one
+// 16-byte bf16 store per pixel and pair instead of two 8-byte ones -- a wave store covers 16 pixels
+// x 64 contiguous bytes.  (The 8-byte form ran the epilogues at ~1 TB/s: 32-byte pieces of
+// 128-byte lines.)  Pure relabeling: LDS layout, swizzle and fragment reads do not change.
+template <bool PERM>
+__device__ __forceinline__ int tile_row_channel(int row) {   // LDS weight-tile row -> channel offset in the tile
+    if (!PERM) return row;
+    return (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+}
+template <bool PERM>
+__device__ __forceinline__ int frag_channel(int b, int q) {  // first of the 4 channels of (fragment b, lane group q)
+    if (!PERM) return b * 16 + q * 4;
+    return (b >> 1) * 32 + q * 8 + (b & 1) * 4;
+}
+
+// Eight consecutive output columns n..n+7 of GEMM row m (bf16 NHWC, vector path): one 16-byte store.
+__device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n, float* f) {
+    if (p.out_layout != VT_OUT_NHWC || p.out_f32 || !p.vec_store) return false;
+    const int HoWo = p.Ho * p.Wo;
+    int64_t opix = m;
+    int co = n;
+    if (p.phases > 1) {
+        const int ph = n / p.cout;
+        co = n - ph * p.cout;
+        const int img = m / HoWo;
+        const int rem = m - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        opix = ((int64_t)img * (2 * p.Ho) + 2 * oy + (ph >> 1)) * (2 * p.Wo) + 2 * ox + (ph & 1);
+    }
+    const int lim = (p.phases > 1) ? p.cout : p.coutT;
+    if (co + 8 > lim || ((p.ld_out | co) & 7) || (p.resid && (p.ld_res & 7))) return false;
+    bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
+    if (p.resid) {
+        float g[8];
+        unpack16<bf16_t>(ld128((const bf16_t*)p.resid + opix * p.ld_res + co), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
+    }
+    st128(o, pack16<bf16_t>(f));
+    return true;
+}
+
 // Epilogue straight from the accumulators.  The kernels issue the MFMAs with the operands
 // swapped (weights as the "A" matrix, pixels as "B"), so the C/D fragment of lane (q, l15) holds
 // FOUR CONSECUTIVE OUTPUT CHANNELS (4q..4q+3) of ONE pixel (l15): bias, activation, residual and
@@ -292,6 +338,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                                               unsigned char* smem, const RowMap rowmap, int n0, int split,
                                               int tile_id) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PERM = (TN % 2 == 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -305,7 +352,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
+                const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b, q);
                 if (m >= 0 && n < p.ldp) {
                     float f[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
                     st128(part + (int64_t)m * p.ldp + n, pack16<float>(f));
@@ -338,7 +385,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
+                const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b, q);
                 float f[4] = {0.f, 0.f, 0.f, 0.f};
                 if (m >= 0 && n < p.ldp) {
                     const float* src = p.partial + (int64_t)m * p.ldp + n;
@@ -356,6 +403,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         }
         // fall through to the fused epilogue below
     }
+    if (p.dbg == 7 && acc[0][0][0] != 123.456f) return;   // ablation (tools/conv_bench.py): no epilogue
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
     // Fused ToRGB (model/stylegan/model.py:383-392): when this tile holds ALL output channels of its
     // pixels, the 1x1 modulated conv C -> 3 that follows a same-resolution StyledConv is three dot
@@ -365,39 +413,52 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     float rp[TM][3];
 #pragma unroll
     for (int a = 0; a < TM; ++a) rp[a][0] = rp[a][1] = rp[a][2] = 0.0f;
+    constexpr int BS = PERM ? 2 : 1;   // fragments finished together: under PERM a pair = 8 consecutive channels
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
-        float bv[4], sv[4], wr[3][4];
+    for (int b0 = 0; b0 < TN; b0 += BS) {
+        int nh[BS];
+        float bv[BS][4], sv[BS][4], wr[BS][3][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nn = n + i;
-            const int co = (p.phases > 1) ? nn % p.cout : nn;
-            bv[i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
-            sv[i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
-        }
-        if (rgbf) {   // wave-uniform: convs without the fusion pay one scalar branch per fragment column
+        for (int h = 0; h < BS; ++h) {
+            const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b0 + h, q);
+            nh[h] = n;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int nc = (n + i < p.coutT) ? n + i : p.coutT - 1;   // clamped: loads stay unconditional
-                const float live = (n + i < p.coutT) ? 1.0f : 0.0f;
+                const int nn = n + i;
+                const int co = (p.phases > 1) ? nn % p.cout : nn;
+                bv[h][i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
+                sv[h][i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
+            }
+            if (rgbf) {   // wave-uniform: convs without the fusion pay one scalar branch per fragment column
 #pragma unroll
-                for (int j = 0; j < 3; ++j) wr[j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
+                for (int i = 0; i < 4; ++i) {
+                    const int nc = (n + i < p.coutT) ? n + i : p.coutT - 1;   // clamped: loads stay unconditional
+                    const float live = (n + i < p.coutT) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) wr[h][j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
+                }
             }
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
-            if (m < 0 || n >= p.coutT) continue;
-            float f[4];
+            if (m < 0 || nh[0] >= p.coutT) continue;
+            float f[4 * BS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, acc[a][b][i], bv[i], ga, sv[i]);
-            if (rgbf) {
+            for (int h = 0; h < BS; ++h) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    rp[a][j] += (f[0] * wr[j][0] + f[1] * wr[j][1]) + (f[2] * wr[j][2] + f[3] * wr[j][3]);
+                for (int i = 0; i < 4; ++i) f[4 * h + i] = conv_finish(p, acc[a][b0 + h][i], bv[h][i], ga, sv[h][i]);
+                if (rgbf && nh[h] < p.coutT) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        rp[a][j] += (f[4 * h] * wr[h][j][0] + f[4 * h + 1] * wr[h][j][1]) +
+                                    (f[4 * h + 2] * wr[h][j][2] + f[4 * h + 3] * wr[h][j][3]);
+                }
             }
-            store_out4(p, m, n, f);
+            if (BS == 2 && nh[1] < p.coutT && store_out8_bf16(p, m, nh[0], f)) continue;
+#pragma unroll
+            for (int h = 0; h < BS; ++h)
+                if (nh[h] < p.coutT) store_out4(p, m, nh[h], f + 4 * h);
         }
     }
     if (!rgbf) return;
@@ -459,6 +520,7 @@ conv_igemm_kernel(const ConvArgs p) {
     constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte vector
     constexpr int BK = 8 * VEC;          // elements per 128-byte tile row
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PERM = (TN % 2 == 0);   // weight rows in fragment order: see tile_row_channel
     static_assert(TM >= 1 && TN >= 1, "wave tile too small");
     constexpr int AI = (BM + 31) / 32, BI = (BN + 31) / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -549,7 +611,7 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int row = rbase + 32 * i;
-            const int n = n0 + row;
+            const int n = n0 + tile_row_channel<PERM>(row);
             u128 v = zero128();
             if (row < BN && n < p.coutT && tap_ok) v = ld128(wgt + (int64_t)n * p.K + k_elem);
             rb[i] = v;
@@ -650,6 +712,7 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int VEC = 16 / ESZ;
     constexpr int BK = 8 * VEC;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PERM = (TN % 2 == 0);   // weight rows in fragment order: see tile_row_channel
     // every wave issues the same number of loads per K-step (counted vmcnt below): tiles are
     // padded to a multiple of 32 rows in LDS; rows beyond the tile fetch the zero sentinel
     constexpr int AI = (BM + 31) / 32, BI = (BN + 31) / 32;
@@ -697,7 +760,7 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
         const int row = (i * 4 + wave) * 8 + lrow;
-        const int n = n0 + row;
+        const int n = n0 + tile_row_channel<PERM>(row);   // weight rows in fragment order (see tile_row_channel)
         woff[i] = (row < BN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
     }
     const BufRsrc r0 = vt_make_rsrc((const char*)p.src0 - g.bias0, g.nrec0);
@@ -858,6 +921,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int VEC = 16 / ESZ;
     constexpr int BK = 8 * VEC;                 // channels per chunk (128 B)
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PERM = (TN % 2 == 0);   // weight rows in fragment order: see tile_row_channel
     constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, PROWS = PH * PW;
     constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch loads per wave per chunk
     constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
@@ -903,7 +967,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
-        const int n = n0 + row;
+        const int n = n0 + tile_row_channel<PERM>(row);   // weight rows in fragment order (see tile_row_channel)
         woff[i] = (row < BN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
     }
     const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
@@ -1045,7 +1109,8 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) wreg[t][b] = ld128(wg + (int64_t)(b * 16 + l15) * p.K + t * 32 + q * 8);
+            for (int b = 0; b < TN; ++b)   // fragment order: (b, lane group q) <-> channels 8q + 4b .. +3
+                wreg[t][b] = ld128(wg + (int64_t)tile_row_channel<true>(b * 16 + l15) * p.K + t * 32 + q * 8);
     }
     const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
@@ -1077,12 +1142,12 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                rwt[j][b][i] = rgbf ? to_f32(((const T*)p.rgb_w)[j * 32 + b * 16 + q * 4 + i]) : 0.0f;
+                rwt[j][b][i] = rgbf ? to_f32(((const T*)p.rgb_w)[j * 32 + frag_channel<true>(b, q) + i]) : 0.0f;
     float bvr[TN][4];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias ? p.bias[b * 16 + q * 4 + i] : 0.0f;
+        for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias ? p.bias[frag_channel<true>(b, q) + i] : 0.0f;
     const float rb0 = (rgbf && p.rgb_bias) ? p.rgb_bias[0] : 0.0f, rb1 = (rgbf && p.rgb_bias) ? p.rgb_bias[1] : 0.0f,
                 rb2 = (rgbf && p.rgb_bias) ? p.rgb_bias[2] : 0.0f;
 
@@ -1150,31 +1215,26 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             for (int a = 0; a < TM; ++a) {
                 const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
                 float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+                float f[8];   // channels 8q .. 8q+7 of this pixel: fragment 0 holds 8q..+3, fragment 1 8q+4..+7
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    const int n = b * 16 + q * 4;
-                    float f[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = acc[a][b][i] + bvr[b][i];
                         if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
-                        f[i] = v * ga;
+                        f[4 * b + i] = v * ga;
                     }
                     if (rgbf) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            r0 += f[i] * rwt[0][b][i];
-                            r1 += f[i] * rwt[1][b][i];
-                            r2 += f[i] * rwt[2][b][i];
+                            r0 += f[4 * b + i] * rwt[0][b][i];
+                            r1 += f[4 * b + i] * rwt[1][b][i];
+                            r2 += f[4 * b + i] * rwt[2][b][i];
                         }
                     }
-                    if (m >= 0) {
-                        u64v v;
-                        v.x = pack_bf16x2(f[0], f[1]);
-                        v.y = pack_bf16x2(f[2], f[3]);
-                        *reinterpret_cast<u64v*>((bf16_t*)p.out + (int64_t)m * p.ld_out + n) = v;
-                    }
                 }
+                // one 16-byte store per lane: the four lane groups write the pixel's 64 bytes
+                if (m >= 0) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + q * 8, pack16<bf16_t>(f));
                 if (rgbf) {
                     if (p.dbg != 3) {
                     r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
@@ -1715,7 +1775,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)
         VT_PATCH(8, 64, 2, 2, 1, 3, 2, true)
         VT_PATCH(8, 16, 4, 1, 1, 3, 2, true)
-        // deep weight ring (5 taps in flight): one chunk per slice = single patch buffer
+        // one chunk per slice = single patch buffer.  Short ring (71 KB: TWO workgroups per CU, the
+        // prologue / epilogue of one overlaps the taps of the other) when the launch runs several
+        // rounds of workgroups; deep ring (5 taps in flight) for the latency-bound single round.
+        {
+            const char* e = getenv("VT_PATCH_OCC2");   // EXPERIMENT switch
+            const bool occ2 = e && e[0] == '1';
+            VT_PATCH(8, 128, 2, 2, 1, 3, 1, one_chunk && occ2)
+        }
         VT_PATCH(8, 128, 2, 2, 1, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 2, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 4, 6, 1, one_chunk)
