@@ -40,6 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #endif
 
+// fp32 slab row length: whole 32-channel fragment groups, so that fragment-order columns stay in the row
+static inline int slab_ld(int cout_total) { return (cout_total + 31) / 32 * 32; }
 constexpr int64_t VT_TICKET_BYTES = 16384;  // split-K arrival counters at the head of the workspace: 4096 tiles
 
 struct ConvArgs {
@@ -68,6 +70,7 @@ struct ConvArgs {
     // split-K: each tile's K range is cut into `splitk` slices of `kps` K-steps; slice s
     // writes raw fp32 accumulators to partial[s][m][ldp] and conv_splitk_reduce finishes.
     int splitk, kps, ldp;
+    int slab_perm;      // slab columns are in fragment order (tile_row_channel), set by the launcher
     float* partial;
     int* tickets;       // per-tile arrival counters (zero between launches) or NULL = two-pass split-K
     int phase;          // 0 = slices + reduce, 1 = slices only, 2 = reduce only (two-pass split-K)
@@ -352,7 +355,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b, q);
+                // slab columns in FRAGMENT order (the reduce pass undoes it): the four lane groups
+                // of a fragment write 64 contiguous bytes per pixel
+                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;
                 if (m >= 0 && n < p.ldp) {
                     float f[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
                     st128(part + (int64_t)m * p.ldp + n, pack16<float>(f));
@@ -385,7 +390,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b, q);
+                const int n = n0 + wn * (TN * 16) + b * 16 + q * 4;   // fragment-order slab column
                 float f[4] = {0.f, 0.f, 0.f, 0.f};
                 if (m >= 0 && n < p.ldp) {
                     const float* src = p.partial + (int64_t)m * p.ldp + n;
@@ -1256,6 +1261,12 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     }
 }
 
+// slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
+// fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
+__device__ __forceinline__ int slab_col4(const ConvArgs& p, int n) {
+    return p.slab_perm ? (n & ~31) + ((n >> 2) & 1) * 16 + ((n >> 3) & 3) * 4 : n;
+}
+
 // Second pass of a split-K convolution: sum the K-slices in slice order (deterministic),
 // then the same bias / activation / gain / residual / layout epilogue as the fused kernel.
 // One thread per (GEMM row, 8 output columns).
@@ -1276,14 +1287,17 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
         }
         const int n = v8 * 8;
         if (n >= p.coutT) continue;
-        const float* src = p.partial + (int64_t)m * p.ldp + n;
+        // channels n..n+3 and n+4..n+7 sit 16 columns apart when the slab is in fragment order
+        const int c0 = slab_col4(p, n);
+        const int dc = slab_col4(p, n + 4) - c0;
+        const float* src = p.partial + (int64_t)m * p.ldp + c0;
         float f[8];
         unpack16<float>(ld128(src), f);
-        unpack16<float>(ld128(src + 4), f + 4);
+        unpack16<float>(ld128(src + dc), f + 4);
         for (int s = 1; s < p.splitk; ++s) {
             float g[8];
             unpack16<float>(ld128(src + s * slab), g);
-            unpack16<float>(ld128(src + s * slab + 4), g + 4);
+            unpack16<float>(ld128(src + s * slab + dc), g + 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] += g[i];
         }
@@ -1349,10 +1363,13 @@ conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks, int 
         }
         for (int px = p_lo + prow; px < p_hi; px += ROWS) {
             const int64_t m = (int64_t)img * hw + px;
-            const float* src = p.partial + m * p.ldp + n;
+            const float* src = p.partial + m * p.ldp;
+            int col[VEC / 4];
+#pragma unroll
+            for (int v = 0; v < VEC; v += 4) col[v / 4] = slab_col4(p, n + v);
             float f[VEC], r[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + v), f + v);
+            for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + col[v / 4]), f + v);
             if (p.resid) unpack16<T>(ld128((const T*)p.resid + m * p.ld_res + n), r);
             for (int s0 = 1; s0 < p.splitk; s0 += SG) {   // slice order 0..S-1: deterministic
                 float g[SG][VEC];
@@ -1360,7 +1377,7 @@ conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks, int 
                 for (int k = 0; k < SG; ++k) {
                     const int s = (s0 + k < p.splitk) ? s0 + k : 0;   // clamped: loads stay unconditional
 #pragma unroll
-                    for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + s * slab + v), g[k] + v);
+                    for (int v = 0; v < VEC; v += 4) unpack16<float>(ld128(src + s * slab + col[v / 4]), g[k] + v);
                 }
 #pragma unroll
                 for (int k = 0; k < SG; ++k) {
@@ -1479,6 +1496,7 @@ template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvArgs& a, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
+    args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;   // matches PERM of the kernel instance
     args.tiles_n = vt_cdiv(a.coutT, BN);
     args.tiles_m = vt_cdiv(a.M, BM);
     const int nk = vt_cdiv(a.K, BK);
@@ -1637,7 +1655,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             t.splitk = (int)sk;
             // the dilated instances exist only in the one-chunk-per-slice form: they need the full
             // split, i.e. a workspace that can hold it -- otherwise run the 1-D kernel
-            const int64_t need_full = (int64_t)units_p * a.M * ((a.coutT + 7) / 8 * 8);
+            const int64_t need_full = (int64_t)units_p * a.M * slab_ld(a.coutT);
             if (a.dil != 1 && (sk != units_p || (units_p > 1 && (!a.partial || need_full > ws_floats_avail))))
                 t.kind = 0, t.bm = 0, t.splitk = 0;
         } else if (a.dil == 1 && a.coutT >= 64) {
@@ -1681,7 +1699,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     }
     if (t.splitk > units) t.splitk = units;
     if (t.splitk > 1) {
-        const int64_t need = (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8);
+        const int64_t need = (int64_t)t.splitk * a.M * slab_ld(a.coutT);
         if (!a.partial || need > ws_floats_avail) t.splitk = 1;  // no workspace: single pass
     }
     if (t.splitk < 1) t.splitk = 1;
@@ -1695,6 +1713,7 @@ template <typename T, int TH, int BN, int WM, int WN, int DIL, int NSTB, int ABU
 int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
+    args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;   // matches PERM of the kernel instance
     args.tiles_n = vt_cdiv(a.coutT, BN);
     args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
     const int units = a.cin / BK;
@@ -1722,6 +1741,7 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
 template <typename T>
 int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     ConvArgs args = a;
+    args.slab_perm = 0;
     args.splitk = 1;
     args.tiles_n = 1;
     args.tiles_m = a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16);
@@ -1746,7 +1766,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
     a.force_generic = hint >= 1000000000;
     const TilePlan t = choose_plan<T>(a, hint % 1000000000, ws_floats);
     a.splitk = t.splitk;
-    a.ldp = (a.coutT + 7) / 8 * 8;
+    a.ldp = slab_ld(a.coutT);
     if (a.rgb_w && (t.bn < a.coutT || t.splitk > 1)) {
         vt_set_error("vt_conv2d: fused ToRGB needs all %d output channels in one tile (plan %dx%d, split %d)",
                      a.coutT, t.bm, t.bn, t.splitk);
@@ -1939,7 +1959,7 @@ extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, big)
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, big);
     if (t.splitk <= 1) return 0;
-    return VT_TICKET_BYTES + (int64_t)t.splitk * a.M * ((a.coutT + 7) / 8 * 8) * 4;
+    return VT_TICKET_BYTES + (int64_t)t.splitk * a.M * slab_ld(a.coutT) * 4;
 }
 
 // ---------------------------------------------------------------------------------
