@@ -86,7 +86,7 @@ def video_rate(eng, style, d_s, H, W, batch, use_graph, n_frames=96):
     g = np.random.default_rng(0)
     frames = g.integers(0, 256, (8, H, W, 3), dtype=np.uint8)
     parsing = (g.standard_normal((8, 19, H, W)) * 4).astype(np.float32)
-    vt = video.VideoToonifier(eng, style, d_s, batch_size=batch, bgr=True, depth=2, use_graph=use_graph)
+    vt = video.VideoToonifier(eng, style, d_s, batch_size=batch, bgr=True, depth=3, use_graph=use_graph)
     sink = lambda i, fr: None
     vt.run(((frames[i % 8], parsing[i % 8]) for i in range(2 * batch)), sink)   # warm-up (plans, graph, pinned buffers)
     torch.cuda.synchronize()
@@ -95,7 +95,7 @@ def video_rate(eng, style, d_s, H, W, batch, use_graph, n_frames=96):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "batch": batch,
-            "what": "host uint8 BGR frames + fp32 parsing maps in, uint8 BGR frames out (pinned, 2 batches in flight)"}
+            "what": "host uint8 BGR frames + fp32 parsing maps in, uint8 BGR frames out (pinned, 3 batches in flight)"}
 
 
 def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--d-s", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("VT_BENCH_LANES", "3")),
+                    help="frames in flight per GPU: step i runs on HIP stream i %% lanes with its own plan buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the PCIe-inclusive video-driver measurement")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
@@ -187,11 +189,18 @@ def main():
     # ---- this rank's shard of the synthetic video, resident in HBM -------------------------
     pool = [synth.synth_frames(B, H, W, seed=1000 * rank + i).to(dev) for i in range(4)]
 
-    def step(i):
-        return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph)
+    lanes = max(1, args.lanes)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(lanes - 1)]
 
-    for i in range(args.warmup):
+    def step(i):
+        ln = i % lanes
+        with torch.cuda.stream(streams[ln]):
+            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=ln)
+
+    for i in range(max(args.warmup, lanes)):
         y = step(i)
+        if i < lanes:
+            torch.cuda.synchronize()   # plan construction + graph capture of each lane, one at a time
     torch.cuda.synchronize()
     assert tuple(y.shape) == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(y).all())
 
@@ -274,6 +283,7 @@ def main():
                                    f"seeded synthetic weights, style path recomputed every frame",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{ws}",
                        "launch": "hipGraph replay" if use_graph else "eager",
+                       "frames_in_flight_per_gpu": lanes,
                        "weight_broadcast_s": t_bcast},
             "roofline": roofline,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}

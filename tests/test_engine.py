@@ -161,3 +161,39 @@ def test_full_size_properties():
     yb = engd.forward(x, s.repeat(2, 1, 1), 0.5)
     assert torch.equal(yb[1:], engd.forward(x[1:].contiguous(), s, 0.5)), "batched == per-frame"
     assert not torch.equal(engd.forward(x[:1].contiguous(), s, 0.0), yb[:1]), "D must depend on d_s"
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_on_separate_lanes():
+    """bench.py / video.py keep several frames of a video in flight on one GPU: frame i runs on
+    HIP stream i % L with engine lane i % L (own activations, split-K workspace and hipGraph).
+    Overlapped frames must be bit-identical to the same frames run one after the other."""
+    from vtoonify_amd import _lib
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    eng = engine("D", torch.bfloat16, dev)
+    s = synth.synth_style(seed=17).to(dev)
+    xs = [synth.synth_frames(1, 256, 256, seed=40 + i).to(dev) for i in range(6)]
+    want = [eng.forward(x, s, 0.5, use_graph=True) for x in xs]
+    torch.cuda.synchronize()
+    L = 3
+    streams = [torch.cuda.Stream(dev) for _ in range(L)]
+    for rounds in range(2):   # first round builds the lanes' plans and graphs, second one is all replay
+        got = []
+        for i, x in enumerate(xs):
+            with torch.cuda.stream(streams[i % L]):
+                got.append(eng.forward(x, s, 0.5, use_graph=True, lane=i % L))
+        torch.cuda.synchronize()
+        for i in range(len(xs)):
+            assert torch.equal(got[i], want[i]), (rounds, i)
+
+
+def test_lanes_are_independent_plans(dev):
+    d, _ = load_golden("e2e_T.npz")
+    eng = engine("T", torch.float32, dev)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    y0 = eng.forward(x, s, 0.5)
+    y1 = eng.forward(x, s, 0.5, lane=1)
+    assert torch.equal(y0, y1)
+    p0, p1 = eng.plan_for(1, x.shape[2], x.shape[3], True, False), eng._plans[(1, x.shape[2], x.shape[3], True, False, 1)]
+    assert p0 is not p1 and p0.bufs["x_nhwc"].data_ptr() != p1.bufs["x_nhwc"].data_ptr()

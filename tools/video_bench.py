@@ -45,7 +45,8 @@ def main():
             e1.synchronize()
             ms = e0.elapsed_time(e1) / 10
             print(f"batch-sized {direction} {name}: {ms:.3f} ms = {hbuf.numel() * hbuf.element_size() / ms / 1e6:.1f} GB/s", flush=True)
-    for batch, depth, with_p in ((1, 2, True), (4, 1, True), (4, 2, True), (4, 3, True), (8, 2, True), (4, 2, False)):
+    for batch, depth, with_p in ((1, 1, True), (1, 2, True), (1, 3, True), (1, 4, True), (2, 2, True), (2, 3, True), (4, 1, True),
+                                 (4, 2, True), (4, 3, True), (8, 2, True), (8, 3, True)):
         vt = video.VideoToonifier(eng, style, 0.5, batch_size=batch, depth=depth)
         src = lambda n: ((frames[i % 8], parsing[i % 8] if with_p else None) for i in range(n))
         if not with_p:

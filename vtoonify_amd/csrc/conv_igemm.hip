@@ -1649,7 +1649,11 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         } else if (a.coutT >= 128 && ptiles(8, 128) < 192 &&
                    (a.dil == 1 || ptiles(8, 128) * units_p <= 1024)) {
             t.bm = 128, t.bn = 128;
-            int64_t sk = (256 + ptiles(8, 128) - 1) / ptiles(8, 128);
+            static const int wg_target = [] {   // EXPERIMENT switch: workgroups a split-K launch aims for
+                const char* e = getenv("VT_SPLITK_WGS");
+                return e && atoi(e) > 0 ? atoi(e) : 256;
+            }();
+            int64_t sk = (wg_target + ptiles(8, 128) - 1) / ptiles(8, 128);
             if (sk > units_p || a.dil != 1) sk = units_p;   // dilated instances: one chunk per slice
             if (sk > 32) sk = 32;
             t.splitk = (int)sk;

@@ -572,7 +572,10 @@ class VToonifyEngine:
     @torch.no_grad()
     def forward(self, x: torch.Tensor, style: torch.Tensor, d_s=None, return_mask: bool = False,
                 return_feat: bool = False, shared_style: Optional[bool] = None,
-                use_graph: bool = False) -> torch.Tensor:
+                use_graph: bool = False, lane: int = 0) -> torch.Tensor:
+        """`lane` selects an independent set of plan buffers (activations, split-K workspace, graph):
+        frames issued on different HIP streams must use different lanes, so that two frames of a
+        video can be in flight on one GPU (frames are independent)."""
         if x.device != self.device and not (x.device.type == self.device.type == "cpu"):
             raise _lib.VtError(f"input on {x.device}, engine on {self.device}")
         B, cin, H, W = x.shape
@@ -592,7 +595,7 @@ class VToonifyEngine:
         if shared_style is None:
             shared_style = style.shape[0] == 1 or B == 1 or self._rows_equal(style)
         has_res = self.dual and d_s != 0.0  # AdaResBlock early-out (dualstylegan.py:40-41)
-        key = (B, H, W, bool(shared_style), has_res)
+        key = (B, H, W, bool(shared_style), has_res) + ((lane,) if lane else ())
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(B, H, W, bool(shared_style), has_res)
