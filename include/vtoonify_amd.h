@@ -152,6 +152,8 @@ typedef struct vt_conv_desc {
                               the compute dtype, phases == 1): the split-K reduce pass emits them while
                               it writes the output, any other plan appends the statistics launch.
                               Consumer: vt_instnorm_apply_stats. */
+    int32_t post_relu;     /* != 0: out = max(v + beta * resid, 0) -- the ReLU that FOLLOWS the shortcut add
+                              of a ResNet BasicBlock (model/bisenet/resnet.py:36-48); 0 = off */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
@@ -284,6 +286,33 @@ int vt_se_apply(void* out, const void* res, const float* gate, const void* short
                 int ow, int c, int sc_h, int sc_w, int sc_stride, int dtype, vt_stream stream);
 int vt_upsample_bilinear_add(void* out, const void* x, const void* y, int n, int h, int w, int H,
                              int W, int c, int dtype, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * Face-parsing network glue (BiSeNet, model/bisenet/model.py:92-254, resnet.py:58-80; the caller
+ * of the hot path that produces 19 of its 22 input channels, style_transfer.py:171-174), NHWC.
+ *   vt_maxpool2d         nn.MaxPool2d(k, stride, pad) (resnet.py:63: 3, 2, 1); out (n,oh,ow,c),
+ *                        oh = (h + 2*pad - k)/stride + 1
+ *   vt_gate_add_nearest  out[n,Y,X,c] = res[n,y,x,c] * gate[n][c] + add_vec[n][c] + add[n,y,x,c],
+ *                        (y,x) = nearest-neighbour source of (Y,X) for an (out_h,out_w) output
+ *                        (F.interpolate(mode='nearest'): floor(dst * in/out)); add_vec / add may be
+ *                        NULL.  ARM attention product + "+ avg_up" / "+ feat32_up" + up-sampling
+ *                        (model.py:78-85, 108-121); with gate = 1 + atten it is also the
+ *                        FeatureFusionModule output feat * atten + feat (model.py:205-207)
+ *   vt_resize_bilinear   F.interpolate(in, (virt_h, virt_w), mode='bilinear', align_corners) * mul on
+ *                        planar fp32 input (n,c,h,w), evaluated at every `step`-th pixel:
+ *                        out[Y][X] = resized[Y*step][X*step], (out_h,out_w) <= ceil(virt/step);
+ *                        output planar fp32/bf16 (VT_OUT_NCHW) or NHWC with pixel stride ld_out
+ *                        (channels >= c are left untouched).  aten's source-index arithmetic
+ *                        (area_pixel_compute_source_index) in fp32.
+ * --------------------------------------------------------------------------------- */
+int vt_maxpool2d(void* out, const void* x, int n, int h, int w, int c, int k, int stride, int pad,
+                 int dtype, vt_stream stream);
+int vt_gate_add_nearest(void* out, const void* res, const float* gate, const float* add_vec,
+                        const void* add, int n, int h, int w, int c, int out_h, int out_w, int dtype,
+                        vt_stream stream);
+int vt_resize_bilinear(void* out, int out_layout, int ld_out, int out_dtype, const float* in, int n,
+                       int c, int h, int w, int virt_h, int virt_w, int align_corners, int step,
+                       int out_h, int out_w, float mul, vt_stream stream);
 
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,

@@ -117,3 +117,27 @@ def test_video_driver_matches_frame_by_frame(dev):
              for r in range(2)]
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == n
     assert all(np.array_equal(got[i], want[i]) for i in range(n))
+
+
+def test_video_driver_computes_parsing_maps_on_the_gpu(dev):
+    """Source yields no parsing maps + a parsing engine: x_p comes from BiSeNet on the device
+    (style_transfer.py:170-172) and must equal parsing_maps() -> frame-by-frame forward."""
+    from vtoonify_amd.bisenet import BiSeNetEngine
+    big = dev.type == "cuda"
+    n, H, W = (7, 64, 96) if big else (3, 32, 32)
+    dtype = torch.bfloat16 if big else torch.float32
+    frames, _, eng, style = _video_case(dev, n, H, W, 2, 2, dtype)
+    bsd = synth.synth_state_dict(load_keys("bisenet"), 0)
+    par = BiSeNetEngine({k: v.to(dev) for k, v in bsd.items()}, 19, dtype, dev)
+    want = []
+    for f in frames:
+        rgb = video.frame_pack(torch.from_numpy(f[None]).to(dev), None, bgr=True)
+        xp = par.parsing_maps(rgb)
+        x = video.frame_pack(torch.from_numpy(f[None]).to(dev), xp, bgr=True)
+        want.append(video.frame_unpack(eng.forward(x, style, None, shared_style=True), bgr=True)[0].cpu().numpy())
+    for batch, depth in ((2, 2), (3, 3)) if big else ((2, 2),):
+        got = {}
+        vt = video.VideoToonifier(eng, style, None, batch_size=batch, bgr=True, depth=depth, parsing_engine=par)
+        assert vt.run(((frames[i], None) for i in range(n)), lambda i, fr: got.__setitem__(i, fr.copy())) == n
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (batch, depth, i)

@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
         ("rgb_weight", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_resid", C.c_void_p), ("rgb_out", C.c_void_p),
         ("splitk_phase", C.c_int32),
         ("stats_part", C.c_void_p),
+        ("post_relu", C.c_int32),
     ]
 
 
@@ -104,6 +105,10 @@ _SIGS = {
                                   C.c_void_p]),
     "vt_se_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "vt_upsample_bilinear_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "vt_maxpool2d": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "vt_gate_add_nearest": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
+    "vt_resize_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 10 +
+                           [C.c_float, C.c_void_p]),
     "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -76,6 +76,7 @@ struct ConvArgs {
     int phase;          // 0 = slices + reduce, 1 = slices only, 2 = reduce only (two-pass split-K)
     int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
     StatRec* stats_part;  // InstanceNorm chunk records of the output (vt_conv_desc.stats_part) or NULL
+    int post_relu;      // vt_conv_desc.post_relu: max(., 0) after the residual add
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -124,6 +125,16 @@ __device__ __forceinline__ u128 affine16(u128 v, const float* sc, const float* s
 }
 
 
+// ReLU after the residual add (ResNet BasicBlock, model/bisenet/resnet.py:36-48): out = max(v + beta*resid, 0)
+__device__ __forceinline__ float post_act(const ConvArgs& p, float x) { return p.post_relu ? fmaxf(x, 0.0f) : x; }
+template <int N>
+__device__ __forceinline__ void post_act_n(const ConvArgs& p, float* f) {
+    if (p.post_relu) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = fmaxf(f[i], 0.0f);
+    }
+}
+
 // Finished values (bias/activation/gain applied) of 8 consecutive output columns n..n+7 of
 // GEMM row m -> NHWC store with the optional residual add and the polyphase pixel shuffle.
 __device__ __forceinline__ void store_nhwc8(const ConvArgs& p, int m, int n, float* f) {
@@ -151,10 +162,11 @@ __device__ __forceinline__ void store_nhwc8(const ConvArgs& p, int m, int n, flo
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
             }
+            post_act_n<8>(p, f);
             st128(o, pack16<float>(f));
             st128(o + 4, pack16<float>(f + 4));
         } else {
-            for (int i = 0; i < nvalid; ++i) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
+            for (int i = 0; i < nvalid; ++i) o[i] = post_act(p, f[i] + (rs ? p.beta * rs[i] : 0.0f));
         }
     } else {
         bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
@@ -166,10 +178,11 @@ __device__ __forceinline__ void store_nhwc8(const ConvArgs& p, int m, int n, flo
 #pragma unroll
                 for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
             }
+            post_act_n<8>(p, f);
             st128(o, pack16<bf16_t>(f));
         } else {
             for (int i = 0; i < nvalid; ++i)
-                o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
+                o[i] = from_f32<bf16_t>(post_act(p, f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f)));
         }
     }
 }
@@ -243,11 +256,12 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
 #pragma unroll
                     for (int i = 0; i < 4; ++i) f[i] += p.beta * g[i];
                 }
+                post_act_n<4>(p, f);
                 st128(o, pack16<float>(f));
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < nvalid) o[i] = f[i] + (rs ? p.beta * rs[i] : 0.0f);
+                    if (i < nvalid) o[i] = post_act(p, f[i] + (rs ? p.beta * rs[i] : 0.0f));
             }
         } else {
             bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
@@ -260,6 +274,7 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
                     f[2] += p.beta * vt_u2f(r.y << 16);
                     f[3] += p.beta * vt_u2f(r.y & 0xffff0000u);
                 }
+                post_act_n<4>(p, f);
                 u64v v;
                 v.x = pack_bf16x2(f[0], f[1]);
                 v.y = pack_bf16x2(f[2], f[3]);
@@ -267,7 +282,7 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < nvalid) o[i] = from_f32<bf16_t>(f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f));
+                    if (i < nvalid) o[i] = from_f32<bf16_t>(post_act(p, f[i] + (rs ? p.beta * to_f32(rs[i]) : 0.0f)));
             }
         }
     } else {
@@ -280,7 +295,7 @@ __device__ __forceinline__ void store_out4(const ConvArgs& p, int m, int n, floa
         for (int i = 0; i < 4; ++i) {
             if (n + i >= p.coutT) break;
             const int64_t off = ((int64_t)img * p.cout + n + i) * HoWo + rem;
-            o[off] = f[i] + (rs ? p.beta * rs[off] : 0.0f);
+            o[off] = post_act(p, f[i] + (rs ? p.beta * rs[off] : 0.0f));
         }
     }
 }
@@ -327,6 +342,7 @@ __device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n,
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
     }
+    post_act_n<8>(p, f);
     st128(o, pack16<bf16_t>(f));
     return true;
 }
@@ -1317,7 +1333,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
             const int rem = m - img * HoWo;
             for (int i = 0; i < 8 && n + i < p.coutT; ++i) {
                 const int64_t off = ((int64_t)img * p.cout + n + i) * HoWo + rem;
-                o[off] = f[i] + (rs ? p.beta * rs[off] : 0.0f);
+                o[off] = post_act(p, f[i] + (rs ? p.beta * rs[off] : 0.0f));
             }
         }
     }
@@ -1391,6 +1407,7 @@ conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks, int 
             for (int i = 0; i < VEC; ++i) {
                 f[i] = conv_finish(p, f[i], bv[i], ga, sv[i]);
                 if (p.resid) f[i] += p.beta * r[i];
+                f[i] = post_act(p, f[i]);
             }
             const u128 packed = pack16<T>(f);
             st128((T*)p.out + m * p.ld_out + n, packed);
@@ -1594,7 +1611,7 @@ static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
     if (a.c0 != 32 || a.c1 != 0 || a.cout != 32 || a.phases != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if (a.splitk > 1) return false;
     // lean epilogue: bf16 NHWC vector stores, bias + (Leaky)ReLU * gain, optional fused ToRGB
-    if (a.out_layout != VT_OUT_NHWC || a.out_f32 || !a.vec_store || a.resid || a.slope_vec || a.alpha_dev) return false;
+    if (a.out_layout != VT_OUT_NHWC || a.out_f32 || !a.vec_store || a.resid || a.slope_vec || a.alpha_dev || a.post_relu) return false;
     if (a.act != VT_ACT_NONE && a.act != VT_ACT_LRELU) return false;
     const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * 2;
     if (n0 >= (((int64_t)1 << 31) - 4096)) return false;
@@ -1860,6 +1877,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     VT_REQUIRE(!d->stats_part || (d->phases == 1 && d->out_layout == VT_OUT_NHWC && d->out_dtype == d->dtype &&
                                   d->cout % 8 == 0 && (d->dtype == VT_BF16 || d->dtype == VT_F32)),
                "vt_conv2d: stats_part needs phases == 1, NHWC output in the compute dtype, cout %% 8 == 0");
+    VT_REQUIRE(!d->post_relu || !d->rgb_weight, "vt_conv2d: post_relu cannot be combined with the fused ToRGB");
     VT_REQUIRE(!d->rgb_weight || (d->rgb_out && d->phases == 1 && d->out_layout == VT_OUT_NHWC && !d->transposed),
                "vt_conv2d: fused ToRGB needs rgb_out, phases == 1 and NHWC output");
     memset(&a, 0, sizeof(a));
@@ -1878,6 +1896,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
         a.dbg = e ? atoi(e) : 0;
     }
     a.alpha_dev = d->alpha_dev;
+    a.post_relu = d->post_relu ? 1 : 0;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;
     a.resid = d->resid;

@@ -94,7 +94,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
                    in_shift=None, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, alpha=1.0, beta=0.0,
                    alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None,
                    tile_hint=0, splitk_ws=None, slope_vec=None, rgb_weight=None, rgb_bias=None, rgb_resid=None,
-                   rgb_out=None, stats_part=None) -> ConvDesc:
+                   rgb_out=None, stats_part=None, post_relu=0) -> ConvDesc:
     """Fill a vt_conv_desc.  Pointers may be tensors or raw ints (sub-views: data_ptr()+offset)."""
     d = ConvDesc()
     d.src0, d.src1 = _ptr(src0), _ptr(src1)
@@ -117,6 +117,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
     d.slope_vec = _ptr(slope_vec)
     d.rgb_weight, d.rgb_bias, d.rgb_resid, d.rgb_out = _ptr(rgb_weight), _ptr(rgb_bias), _ptr(rgb_resid), _ptr(rgb_out)
     d.stats_part = _ptr(stats_part)
+    d.post_relu = int(post_relu)
     if splitk_ws is not None:  # fp32 workspace tensor enabling split-K (see vt_conv2d_ws_bytes)
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     return d

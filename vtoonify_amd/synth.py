@@ -74,6 +74,16 @@ def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
         if ".res_layer." in key:
             return randn(0.5 * math.sqrt(2.0 / fan_in))
 
+    # --- BiSeNet face parsing (model/bisenet): eval-mode BatchNorm affine ~ (1, 0) -----------
+    if key.startswith(("cp.", "ffm.", "conv_out")) and len(shape) == 1 and leaf in ("weight", "bias"):
+        return (1.0 + randn(0.1)) if leaf == "weight" else randn(0.1)
+    if key.startswith(("cp.", "ffm.", "conv_out")) and len(shape) == 4 and leaf == "weight":
+        # 0.6 x He init keeps the activations O(10) through the 8 residual blocks; small attention
+        # convs keep the sigmoid gates of ARM / FFM off saturation (a saturated gate hides errors)
+        fan_in = shape[1] * shape[2] * shape[3]
+        scale = 0.2 if "conv_atten" in key else 2.0 if key in ("ffm.conv1.weight", "ffm.conv2.weight") else 0.6
+        return randn(scale * math.sqrt(2.0 / fan_in))
+
     # --- buffers with fixed semantics -------------------------------------------------
     if key.endswith("blur.kernel"):
         # ModulatedConv2d(upsample=True): Blur(kernel, upsample_factor=2) -> *4

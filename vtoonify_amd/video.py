@@ -18,8 +18,10 @@ its own engine lane (plan buffers + hipGraph): the kernels of consecutive batche
 GPU, which is worth +37 % (2 in flight) / +50 % (3) frames/s at one frame per batch, where most
 launches of a frame are too small to fill 256 CUs on their own.  One process per GPU; a multi-GPU job cuts the
 frame range with frames.shard_range and every rank runs this loop on its shard (no per-frame
-communication).  The parsing maps are an input (the reference's --parsing_map_path branch,
-style_transfer.py:168-169); BiSeNet itself is out of scope here.
+communication).  The parsing maps are either an input (the reference's --parsing_map_path branch,
+style_transfer.py:168-169) or, when the source yields None for them and a `parsing_engine`
+(vtoonify_amd.bisenet.BiSeNetEngine) is given, computed on the GPU from the frame itself
+(style_transfer.py:170-172) in the same compute stream, before the frame is packed.
 """
 from __future__ import annotations
 
@@ -77,12 +79,14 @@ def _stream(t: torch.Tensor):
 class _Slot:
     """Staging buffers of one in-flight batch."""
 
-    def __init__(self, B, H, W, pc, device, lane=0):
+    def __init__(self, B, H, W, pc, device, lane=0, host_parsing=True):
         cuda = device.type == "cuda"
         self.lane = lane
         self.compute = torch.cuda.Stream(device) if cuda else None
         self.h_frames = torch.empty((B, H, W, 3), dtype=torch.uint8, pin_memory=cuda)
-        self.h_parsing = torch.empty((B, pc, H, W), dtype=torch.float32, pin_memory=cuda) if pc else None
+        self.h_parsing = (torch.empty((B, pc, H, W), dtype=torch.float32, pin_memory=cuda)
+                          if pc and host_parsing else None)
+        self.d_rgb = torch.empty((B, 3, H, W), dtype=torch.float32, device=device) if pc and not host_parsing else None
         self.h_out = torch.empty((B, 4 * H, 4 * W, 3), dtype=torch.uint8, pin_memory=cuda)
         self.d_frames = torch.empty((B, H, W, 3), dtype=torch.uint8, device=device)
         self.d_parsing = torch.empty((B, pc, H, W), dtype=torch.float32, device=device) if pc else None
@@ -95,7 +99,7 @@ class _Slot:
         # torch's CPU copy spreads a 5 MB copy over the intra-op thread pool, whose wake-up after the
         # main thread has slept in an event wait costs milliseconds per frame
         self.n_frames = self.h_frames.numpy()
-        self.n_parsing = self.h_parsing.numpy() if pc else None
+        self.n_parsing = self.h_parsing.numpy() if self.h_parsing is not None else None
         self.n_out = self.h_out.numpy()
         self.count = 0
         self.first = 0
@@ -108,7 +112,7 @@ class VideoToonifier:
     are (4H,4W,3) uint8 in the same channel order."""
 
     def __init__(self, engine, style: torch.Tensor, d_s: Optional[float], batch_size: int = 4, bgr: bool = True,
-                 depth: int = 2, use_graph: bool = True):
+                 depth: int = 2, use_graph: bool = True, parsing_engine=None, parsing_channels: int = 19):
         if batch_size < 1 or depth < 1:
             raise ValueError("batch_size and depth must be >= 1")
         self.engine, self.style, self.d_s = engine, style, d_s
@@ -116,6 +120,7 @@ class VideoToonifier:
         self.device = engine.device
         self.cuda = self.device.type == "cuda"
         self.use_graph = use_graph and self.cuda
+        self.parsing_engine, self.parsing_channels = parsing_engine, parsing_channels
         self._slots: List[_Slot] = []
         self._geom = None
         if self.cuda:
@@ -125,21 +130,23 @@ class VideoToonifier:
             self.copy_down = torch.cuda.Stream(self.device)
 
     # -- one batch through the three stages -------------------------------------------------
-    def _slots_for(self, H, W, pc):
-        if self._geom != (H, W, pc):
+    def _slots_for(self, H, W, pc, host_parsing=True):
+        if self._geom != (H, W, pc, host_parsing):
             if H % 8 or W % 8:
                 raise _lib.VtError("frame height and width must be multiples of 8 (util.py:184-187)")
-            self._slots = [_Slot(self.B, H, W, pc, self.device, lane=i) for i in range(self.depth)]
-            self._geom = (H, W, pc)
+            self._slots = [_Slot(self.B, H, W, pc, self.device, lane=i, host_parsing=host_parsing)
+                           for i in range(self.depth)]
+            self._geom = (H, W, pc, host_parsing)
         return self._slots
 
     def _submit(self, slot: _Slot, n: int):
         """Upload, compute, download `n` staged frames of `slot` (asynchronous on CUDA)."""
-        pc = 0 if slot.h_parsing is None else slot.h_parsing.shape[1]
+        pc = 0 if slot.d_parsing is None else slot.d_parsing.shape[1]
+        host_p = slot.h_parsing is not None
         if self.cuda:
             with torch.cuda.stream(self.copy_up):
                 slot.d_frames[:n].copy_(slot.h_frames[:n], non_blocking=True)
-                if pc:
+                if host_p:
                     slot.d_parsing[:n].copy_(slot.h_parsing[:n], non_blocking=True)
                 slot.ev_up.record(self.copy_up)
             with torch.cuda.stream(slot.compute):
@@ -152,12 +159,17 @@ class VideoToonifier:
                 slot.ev_down.record(self.copy_down)
         else:
             slot.d_frames[:n].copy_(slot.h_frames[:n])
-            if pc:
+            if host_p:
                 slot.d_parsing[:n].copy_(slot.h_parsing[:n])
             self._compute(slot, n, pc)
             slot.h_out[:n].copy_(slot.d_out[:n])
 
     def _compute(self, slot: _Slot, n: int, pc: int):
+        if slot.d_rgb is not None:
+            # no parsing maps from the source: x_p = nearest_x0.5(BiSeNet(2 * bilinear_x2(x))[0]) on the
+            # GPU (style_transfer.py:170-172); the /16 is vt_frame_pack's parsing_scale
+            rgb = frame_pack(slot.d_frames[:n], None, self.bgr, out=slot.d_rgb[:n])
+            self.parsing_engine.parsing_maps(rgb, use_graph=self.use_graph, lane=slot.lane, out=slot.d_parsing[:n])
         x = frame_pack(slot.d_frames[:n], slot.d_parsing[:n] if pc else None, self.bgr, out=slot.d_x[:n])
         y = self.engine.forward(x, self.style, self.d_s, shared_style=True, use_graph=self.use_graph,
                                 lane=slot.lane)
@@ -186,8 +198,9 @@ class VideoToonifier:
                     done = True
                 if batch:
                     f0, p0 = batch[0]
-                    pc = 0 if p0 is None else p0.shape[0]
-                    slots = self._slots_for(f0.shape[0], f0.shape[1], pc)
+                    host_p = p0 is not None or self.parsing_engine is None
+                    pc = (0 if p0 is None else p0.shape[0]) if host_p else self.parsing_channels
+                    slots = self._slots_for(f0.shape[0], f0.shape[1], pc, host_p)
                     slot = slots[k % self.depth]
                     k += 1
                     if slot in pending:   # the ring is full: retire the oldest batch first
@@ -196,7 +209,7 @@ class VideoToonifier:
                         if f.shape != f0.shape or f.dtype != np.uint8:
                             raise _lib.VtError("all frames of a video must share one (H,W,3) uint8 shape")
                         np.copyto(slot.n_frames[j], f)
-                        if pc:
+                        if pc and host_p:
                             np.copyto(slot.n_parsing[j], p, casting="same_kind")
                     slot.count, slot.first = len(batch), idx
                     idx += len(batch)
