@@ -6,7 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (VToonify.forward, model/vtoonify.py:210-277 of the
-reference) over one batch of synthetic frames already resident in HBM.  The workload at
+reference) over one batch of synthetic frames already resident in HBM.  Frames of a video are
+independent, so --lanes L (default 3) keeps L steps in flight on L HIP streams, each
+with its own plan buffers and hipGraph: step i is issued on stream i % L.  Every step still does
+the whole frame; `single_stream` in the JSON line is the same workload with one frame in flight.  The workload at
 N=1 is BASELINE.json configs[1]: a single 22x256x256 frame -> 3x1024x1024, VToonify-D,
 bf16 compute (fp32 accumulate / statistics / RGB skip path), seeded synthetic weights.
 Nothing is cached across steps: the style path (T_c/T_s linears, weight modulation +
@@ -158,6 +161,12 @@ def main():
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table (stderr)")
     args = ap.parse_args()
 
+    if args.lanes > 1:
+        # split-K launches aim for 128 workgroups instead of one per CU (256): with several frames in
+        # flight the other frames fill the chip, and the fp32 slabs a split writes and re-reads halve
+        # (measured, same box, lanes 3: 760 vs 733 frames/s; one frame in flight: 460 vs 490).
+        # Read once by the library at its first plan query.
+        os.environ.setdefault("VT_SPLITK_WGS", "128")
     from vtoonify_amd import _lib, frames, synth
     from vtoonify_amd.engine import VToonifyEngine
 
@@ -218,6 +227,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the same workload with ONE frame in flight (latency view; not `value`)
+    single = None
+    if rank == 0 and lanes > 1:
+        n1 = min(args.steps, 20)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n1):
+            eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0)
+        torch.cuda.synchronize()
+        single = {"value": n1 * B / (time.perf_counter() - t1), "unit": "frames/s", "steps": n1,
+                  "ms_per_step": 1e3 * (time.perf_counter() - t1) / n1, "frames_in_flight": 1}
 
     result = None
     if rank == 0:
@@ -284,8 +305,10 @@ def main():
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{ws}",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "frames_in_flight_per_gpu": lanes,
+                       "splitk_workgroup_target": int(os.environ.get("VT_SPLITK_WGS", "256")),
                        "weight_broadcast_s": t_bcast},
             "roofline": roofline,
+            "single_stream": single,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                         for r in rows[:8]],
         }

@@ -1623,6 +1623,10 @@ static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
 template <typename T>
 static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
+    static const int wg_target = [] {   // EXPERIMENT switch: workgroups a split-K launch aims for (256 = one per CU)
+        const char* e = getenv("VT_SPLITK_WGS");
+        return e && atoi(e) > 0 ? atoi(e) : 256;
+    }();
     TilePlan t;
     t.kind = 0;
     t.bm = t.bn = 0;
@@ -1666,10 +1670,6 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         } else if (a.coutT >= 128 && ptiles(8, 128) < 192 &&
                    (a.dil == 1 || ptiles(8, 128) * units_p <= 1024)) {
             t.bm = 128, t.bn = 128;
-            static const int wg_target = [] {   // EXPERIMENT switch: workgroups a split-K launch aims for
-                const char* e = getenv("VT_SPLITK_WGS");
-                return e && atoi(e) > 0 ? atoi(e) : 256;
-            }();
             int64_t sk = (wg_target + ptiles(8, 128) - 1) / ptiles(8, 128);
             if (sk > units_p || a.dil != 1) sk = units_p;   // dilated instances: one chunk per slice
             if (sk > 32) sk = 32;
@@ -1710,9 +1710,9 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         // too few tiles to fill 256 CUs: cut K so that ~512 workgroups exist
         t.splitk = 1;
         const int min_units = t.kind == 1 ? 1 : 2;
-        const int64_t enough = t.kind == 1 && t.bm == 256 ? 192 : 384;  // 8-wave tiles: 1 WG fills a CU
+        const int64_t enough = (t.kind == 1 && t.bm == 256 ? 192 : 384) * wg_target / 256;  // 8-wave tiles: 1 WG fills a CU
         if (ntiles < enough && units >= 2 * min_units) {
-            int64_t sk = (512 + ntiles - 1) / ntiles;
+            int64_t sk = (2 * wg_target + ntiles - 1) / ntiles;
             if (sk > units / min_units) sk = units / min_units;
             if (sk > 32) sk = 32;
             t.splitk = (int)sk;
