@@ -161,12 +161,10 @@ def main():
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table (stderr)")
     args = ap.parse_args()
 
-    if args.lanes > 1:
-        # split-K launches aim for 128 workgroups instead of one per CU (256): with several frames in
-        # flight the other frames fill the chip, and the fp32 slabs a split writes and re-reads halve
-        # (measured, same box, lanes 3: 760 vs 733 frames/s; one frame in flight: 460 vs 490).
-        # Read once by the library at its first plan query.
-        os.environ.setdefault("VT_SPLITK_WGS", "128")
+    # VT_SPLITK_WGS (read once by the library): workgroups a split-K launch aims for, default 256 = one
+    # per CU.  128 halves the fp32 slabs a split writes and re-reads and measured +3.9 % frames/s with
+    # three frames in flight (760 vs 733, same box) but -6 % with one (460 vs 490) and slower trunk
+    # launches in the per-kernel pass; the default stays 256.
     from vtoonify_amd import _lib, frames, synth
     from vtoonify_amd.engine import VToonifyEngine
 
