@@ -210,6 +210,10 @@ def main():
             torch.cuda.synchronize()   # plan construction + graph capture of each lane, one at a time
     torch.cuda.synchronize()
     assert tuple(y.shape) == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(y).all())
+    # fingerprint of the last warm-up frame: lets two runs (A/B switches, boxes) be compared for equal results
+    yf = y.float()
+    checksum = {"mean_abs": float(yf.abs().mean()), "max_abs": float(yf.abs().max()),
+                "samples": [float(v) for v in yf.flatten()[:: max(1, yf.numel() // 8)][:8]]}
 
     if dist.is_initialized():
         dist.barrier()
@@ -307,6 +311,7 @@ def main():
                        "weight_broadcast_s": t_bcast},
             "roofline": roofline,
             "single_stream": single,
+            "output_checksum": checksum,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                         for r in rows[:8]],
         }

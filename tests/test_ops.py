@@ -548,3 +548,16 @@ def test_instnorm_adain_fusion_pack(dev, dtype):
     t = 1e-6 if dtype == torch.float32 else 8e-3
     assert rel_err(o_[..., :3], skip.transpose(0, 2, 3, 1)) < t and np.abs(o_[..., 3:8]).max() == 0
     assert rel_err(o_[..., 8:], xq.transpose(0, 2, 3, 1) * mask[..., None]) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_patch_small_tile_whole_k(dev, dtype):
+    """64-pixel x 64-channel patch instances (VT_FULLK plans): whole K range in one workgroup, or a
+    few slices, for dilation 1 / 2 / 4; several channel chunks per workgroup (patch double buffer)."""
+    t = F32_TOL if dtype == torch.float32 else 8e-3
+    L = K.ACT_LRELU
+    for dil in (1, 2, 4):
+        for s in (0, 1, 2):
+            hint = P + s * 1000000 + 64064
+            assert _conv_case(dev, dtype, 2, 192, 9, 21, 136, 3, 1, dil, dil, act=L, hint=hint, resid=True, ws=True,
+                              seed=dil * 10 + s, expect_kind=1) < t, (dil, s)

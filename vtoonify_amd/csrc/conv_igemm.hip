@@ -1627,6 +1627,10 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         const char* e = getenv("VT_SPLITK_WGS");
         return e && atoi(e) > 0 ? atoi(e) : 256;
     }();
+    static const int fullk = [] {
+        const char* e = getenv("VT_FULLK");
+        return e ? atoi(e) : 0;
+    }();
     TilePlan t;
     t.kind = 0;
     t.bm = t.bn = 0;
@@ -1667,6 +1671,11 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             t.bm = 256, t.bn = 128;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
             t.bm = 256, t.bn = 64;
+        } else if (fullk > 0 && a.coutT >= 128 && a.coutT % 64 == 0 && ptiles(8, 128) < 192 && ptiles(4, 64) >= 96) {
+            // EXPERIMENT (VT_FULLK=n): 64-pixel x 64-channel tiles that keep (1/n of) the whole K range in
+            // one workgroup -- no (n = 1) or n-slice fp32 slabs instead of one slab per channel chunk
+            t.bm = 64, t.bn = 64;
+            t.splitk = fullk < units_p ? fullk : units_p;
         } else if (a.coutT >= 128 && ptiles(8, 128) < 192 &&
                    (a.dil == 1 || ptiles(8, 128) * units_p <= 1024)) {
             t.bm = 128, t.bn = 128;
@@ -1816,6 +1825,9 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)
         VT_PATCH(8, 64, 2, 2, 1, 3, 2, true)
         VT_PATCH(8, 16, 4, 1, 1, 3, 2, true)
+        VT_PATCH(4, 64, 2, 2, 1, 4, 2, true)   // VT_FULLK experiment: whole-K (or few-slice) small tiles
+        VT_PATCH(4, 64, 2, 2, 2, 4, 2, true)
+        VT_PATCH(4, 64, 2, 2, 4, 4, 2, true)
         // one chunk per slice = single patch buffer.  Short ring (71 KB: TWO workgroups per CU, the
         // prologue / epilogue of one overlaps the taps of the other) when the launch runs several
         // rounds of workgroups; deep ring (5 taps in flight) for the latency-bound single round.
