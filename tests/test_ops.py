@@ -471,8 +471,49 @@ def test_conv2d_gradfix_surface(dev):
     wt = (g.standard_normal((6, 5, 3, 3)) / 5).astype(np.float32)
     yt = op.conv2d_gradfix.conv_transpose2d(T(x, dev), T(wt, dev), stride=2, padding=0)
     assert rel_err(yt.cpu().numpy(), O.conv_transpose2d(x, wt, 2)) < F32_TOL
-    with pytest.raises(NotImplementedError):
-        op.conv2d_gradfix.conv2d(T(x, dev).requires_grad_(True), T(w, dev), groups=2)
+
+
+def _gradfix_case(dev, transposed, N, Ci, H, W, Co, k, s, p, d, groups=1, opad=0, seed=0):
+    """conv2d_gradfix autograd (first and second order) against torch's own autograd of F.conv2d /
+    F.conv_transpose2d on the CPU -- what the reference's Conv2d / Conv2dGradWeight Functions
+    (op/conv2d_gradfix.py:134-223) delegate to."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(N, Ci, H, W, generator=g)
+    w0 = torch.randn((Ci, Co // groups, k, k) if transposed else (Co, Ci // groups, k, k), generator=g) / 3
+    b0 = torch.randn(Co, generator=g)
+    x, w, b = [t.clone().to(dev).requires_grad_(True) for t in (x0, w0, b0)]
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x0, w0, b0)]
+    if transposed:
+        y = op.conv2d_gradfix.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=opad, groups=groups, dilation=d)
+        yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=opad, groups=groups, dilation=d)
+    else:
+        y = op.conv2d_gradfix.conv2d(x, w, b, stride=s, padding=p, dilation=d, groups=groups)
+        yr = F.conv2d(xr, wr, br, stride=s, padding=p, dilation=d, groups=groups)
+    go = torch.randn(yr.shape, generator=g)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go.to(dev), create_graph=True)
+    rx, rw, rb = torch.autograd.grad(yr, (xr, wr, br), go, create_graph=True)
+    u, v = torch.randn(rx.shape, generator=g), torch.randn(rw.shape, generator=g)
+    hx, hw = torch.autograd.grad((gx * u.to(dev)).sum() + (gw * v.to(dev)).sum(), (x, w))   # R1-style second order
+    qx, qw = torch.autograd.grad((rx * u).sum() + (rw * v).sum(), (xr, wr))
+    pairs = ((y, yr), (gx, rx), (gw, rw), (gb, rb), (hx, qx), (hw, qw))
+    return max(rel_err(a.detach().cpu().numpy(), r.detach().numpy()) for a, r in pairs)
+
+
+def test_conv2d_gradfix_autograd(dev):
+    assert _gradfix_case(dev, False, 2, 8, 9, 7, 6, 3, 1, 1, 1) < F32_TOL
+    assert _gradfix_case(dev, False, 2, 4, 10, 9, 8, 3, 2, 1, 1, seed=1) < F32_TOL          # stride 2, odd sizes
+    assert _gradfix_case(dev, False, 1, 8, 9, 9, 4, 3, 1, 2, 2, seed=2) < F32_TOL           # dilation 2
+    assert _gradfix_case(dev, True, 2, 6, 5, 4, 8, 3, 2, 0, 1, seed=3) < F32_TOL            # StyledConv up-sampling form
+    assert _gradfix_case(dev, True, 2, 6, 5, 6, 8, 3, 2, 1, 1, opad=1, seed=4) < F32_TOL
+    assert _gradfix_case(dev, False, 2, 8, 6, 6, 6, 3, 1, 1, 1, groups=2, seed=5) < F32_TOL  # ModulatedConv2d: groups = batch
+    assert _gradfix_case(dev, True, 2, 8, 5, 5, 6, 3, 2, 0, 1, groups=2, seed=6) < F32_TOL
+    # no_weight_gradients() (util.py:76: path-length regulariser) suppresses grad_weight only
+    x = torch.randn(1, 8, 6, 6).to(dev).requires_grad_(True)
+    w = torch.randn(4, 8, 3, 3).to(dev).requires_grad_(True)
+    with op.conv2d_gradfix.no_weight_gradients():
+        gx, gw = torch.autograd.grad(op.conv2d_gradfix.conv2d(x, w, padding=1).sum(), (x, w), allow_unused=True)
+    assert gx is not None and gw is None
 
 
 # ---------------------------------------------------------------- style ops / norm / glue

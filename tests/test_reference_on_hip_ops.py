@@ -54,3 +54,79 @@ def test_reference_graph_runs_on_the_drop_in_ops(tmp_path, tag, bb):
                        timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "REL_ERR" in r.stdout
+
+
+_GRAD_WORKER = r"""
+import importlib, os, sys
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REPO, REF, mode, out = sys.argv[1:5]
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np, torch
+sys.path.insert(0, REF)
+import model.stylegan
+if mode == "hip":
+    from vtoonify_amd import _lib
+    from emu import build_emu
+    _lib.use_library(build_emu.build())
+    import vtoonify_amd.op as ops
+    gf = ops.conv2d_gradfix
+else:                                          # the reference's CPU operator twin (op_cpu/readme.md:5-12)
+    ops = importlib.import_module("model.stylegan.op_cpu")
+    gf = importlib.import_module("model.stylegan.op_cpu.conv2d_gradfix")
+    ops.conv2d_gradfix = gf
+sys.modules["model.stylegan.op"] = ops
+sys.modules["model.stylegan.op.conv2d_gradfix"] = gf
+from model.stylegan.model import StyledConv, ToRGB      # reference model code
+torch.manual_seed(0)
+up = StyledConv(16, 8, 3, 32, upsample=True)
+same = StyledConv(8, 8, 3, 32)
+rgb = ToRGB(8, 32, upsample=False)
+for m in (up, same):
+    torch.nn.init.normal_(m.activate.bias, std=0.1)
+params = [p for m in (up, same, rgb) for p in m.parameters() if p.requires_grad]
+x = torch.randn(2, 16, 6, 5, requires_grad=True)
+s = torch.randn(2, 32, requires_grad=True)
+proj = torch.randn(2, 3, 12, 10)
+y = up(x, s, noise=torch.zeros(2, 1, 12, 10))
+y = same(y, s, noise=torch.zeros(2, 1, 12, 10))
+img = rgb(y, s)
+g1 = torch.autograd.grad((img * proj).sum(), [x, s] + params, create_graph=True, allow_unused=True)
+# path-length-style second order (g_path_regularize, util.py:91-99): d(image)/d(latent), squared, back-propagated
+g2 = torch.autograd.grad(g1[1].pow(2).sum(), [x] + params, retain_graph=True, allow_unused=True)
+# R1-style second order (d_r1_loss, util.py:75-82): d(output)/d(input) under no_weight_gradients(), squared
+with gf.no_weight_gradients():
+    gx, = torch.autograd.grad(img.sum(), [x], create_graph=True)
+g3 = torch.autograd.grad(gx.pow(2).sum(), params, allow_unused=True)
+res = {"img": img.detach().numpy()}
+for i, g in enumerate(g1):
+    if g is not None: res[f"g1_{i}"] = g.detach().numpy()
+for i, g in enumerate(g2):
+    if g is not None: res[f"g2_{i}"] = g.detach().numpy()
+for i, g in enumerate(g3):
+    if g is not None: res[f"g3_{i}"] = g.detach().numpy()
+np.savez(out, **res)
+print("SAVED", len(res))
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "model")), reason="reference tree not present")
+def test_reference_training_graph_backpropagates_through_the_drop_in_ops(tmp_path):
+    """The reference's StyledConv(upsample) -> StyledConv -> ToRGB (model/stylegan/model.py:323-392) with
+    `model.stylegan.op` swapped for vtoonify_amd.op: first-order gradients, path-length-style second-order
+    gradients (util.py:91-99) and R1-style ones under no_weight_gradients() (util.py:75-82) must equal
+    those of its op_cpu path."""
+    import numpy as np
+    script = tmp_path / "gworker.py"
+    script.write_text(_GRAD_WORKER)
+    outs = {}
+    for mode in ("cpu", "hip"):
+        out = str(tmp_path / f"g_{mode}.npz")
+        r = subprocess.run([sys.executable, str(script), REPO, REF, mode, out], capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0 and "SAVED" in r.stdout, (mode, r.stdout[-1000:], r.stderr[-3000:])
+        outs[mode] = dict(np.load(out))
+    assert set(outs["cpu"]) == set(outs["hip"]) and len(outs["cpu"]) > 12
+    for k, ref in outs["cpu"].items():
+        err = float(np.abs(outs["hip"][k] - ref).max() / max(np.abs(ref).max(), 1e-30))
+        assert err < 2e-4, (k, err)

@@ -97,7 +97,7 @@ def test_video_driver_matches_frame_by_frame(dev):
     n, H, W = (11, 64, 96) if big else (4, 16, 24)
     frames, parsing, eng, style = _video_case(dev, n, H, W, 2, 2, torch.bfloat16 if big else torch.float32)
     want = _expected(eng, style, frames, parsing, dev)
-    for batch, depth in (((2, 2), (4, 1), (3, 3)) if big else ((3, 2), (1, 1))):
+    for batch, depth in (((2, 2), (4, 1), (3, 3)) if big else ((3, 2),)):   # every in-flight slot builds its own plan
         got = {}
         vt = video.VideoToonifier(eng, style, None, batch_size=batch, bgr=True, depth=depth)
         order = []

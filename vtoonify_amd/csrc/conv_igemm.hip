@@ -1627,6 +1627,10 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         const char* e = getenv("VT_SPLITK_WGS");
         return e && atoi(e) > 0 ? atoi(e) : 256;
     }();
+    static const bool small_lds = [] {
+        const char* e = getenv("VT_SMALL_LDS");
+        return e && e[0] == '1';
+    }();
     static const int fullk = [] {
         const char* e = getenv("VT_FULLK");
         return e ? atoi(e) : 0;
@@ -1667,6 +1671,10 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         const int units_p = a.cin / BK;
         if (a.dil == 1 && a.coutT <= 16) {
             t.bm = 128, t.bn = 16;
+        } else if (small_lds && a.dil == 1 && a.coutT >= 64 && ptiles(16, 64) >= 192) {
+            // EXPERIMENT (VT_SMALL_LDS=1): 72 KB instances only, so that two workgroups -- of this launch or
+            // of another frame in flight -- share a CU (the 256-pixel tiles take 144 KB)
+            t.bm = 128, t.bn = 64;
         } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
             t.bm = 256, t.bn = 128;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {

@@ -4,9 +4,19 @@ module globals `enabled` / `weight_gradients_disabled`, `no_weight_gradients()`,
 
 On the reference every call ends in cuDNN via F.conv2d / F.conv_transpose2d; here GPU
 tensors run the MFMA implicit-GEMM kernel of libvtoonify_amd.so (fp32 inputs use the exact
-fp32 MFMA, bf16 inputs the bf16 MFMA).  Forward only: tensors that require grad are
-rejected (training is out of scope for this path).  `groups` (the
-per-sample trick of ModulatedConv2d, model.py:273-304) is a loop of launches.
+fp32 MFMA, bf16 inputs the bf16 MFMA).  `groups` (the per-sample trick of ModulatedConv2d,
+model.py:273-304) is a loop of launches.
+
+Autograd follows the reference's structure (op/conv2d_gradfix.py:134-223), every contraction on the
+same HIP kernel family:
+  grad_input   = the opposite convolution of grad_output with the weight (conv <-> conv_transpose,
+                 output_padding from the shapes, :122-132), itself differentiable;
+  grad_weight  = Conv2dGradWeight (honours `weight_gradients_disabled`): the batch axis becomes the
+                 contraction axis -- dW[co,ci] = conv2d(x^T (Ci,N,H,W), g^T (Co,N,Ho,Wo) as filters,
+                 stride = dilation, dilation = stride)[:, :, :kh, :kw] -- where the reference calls
+                 cudnn_convolution_backward_weight; its backward gives the second-order terms
+                 (R1 / path-length regularisers, util.py:75-82);
+  grad_bias    = grad_output.sum((0, 2, 3)).
 """
 import contextlib
 
@@ -35,19 +45,26 @@ def _one(v, what):
     return int(v)
 
 
+def _pair(v, what):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2:
+            raise ValueError(f"{what} must be an int or a pair")
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
 def _check(input, weight):
-    if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
-        raise NotImplementedError("vtoonify_amd.op.conv2d_gradfix is inference-only (no autograd)")
     if input.ndim != 4 or weight.ndim != 4:
         raise ValueError("expected 4-D input and weight")
     if input.dtype not in (torch.float32, torch.bfloat16):
         raise NotImplementedError("conv2d_gradfix supports fp32 and bf16 inputs")
 
 
-def _run(input, weight, bias, stride, padding, dilation, groups, transposed, output_padding):
+def _launch(input, weight, bias, stride, padding, dilation, groups, transposed, output_padding):
+    """One forward contraction (no autograd): F.conv2d / F.conv_transpose2d semantics."""
     _check(input, weight)
     stride, padding, dilation = _one(stride, "stride"), _one(padding, "padding"), _one(dilation, "dilation")
-    output_padding = _one(output_padding, "output_padding")
+    oph, opw = _pair(output_padding, "output_padding")
     dtype = input.dtype
     n, cin, h, w = input.shape
     if transposed:
@@ -55,10 +72,8 @@ def _run(input, weight, bias, stride, padding, dilation, groups, transposed, out
         if cin_w != cin:
             raise ValueError("conv_transpose2d: weight.shape[0] must equal input channels")
         cout = cout_g * groups
-        out_h = (h - 1) * stride - 2 * padding + dilation * (kh - 1) + output_padding + 1
-        out_w = (w - 1) * stride - 2 * padding + dilation * (kw - 1) + output_padding + 1
-        # gather form: iy = (oy + p_eff - ky*dil) / stride with p_eff = padding
-        pad_eff = padding
+        out_h = (h - 1) * stride - 2 * padding + dilation * (kh - 1) + oph + 1
+        out_w = (w - 1) * stride - 2 * padding + dilation * (kw - 1) + opw + 1
     else:
         cout, cin_g, kh, kw = weight.shape
         if cin_g * groups != cin:
@@ -66,7 +81,8 @@ def _run(input, weight, bias, stride, padding, dilation, groups, transposed, out
         cout_g = cout // groups
         out_h = (h + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
         out_w = (w + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
-        pad_eff = padding
+    if out_h <= 0 or out_w <= 0:
+        raise ValueError("convolution output would be empty")
     cin_g = cin // groups
     cpad = (cin_g + 7) // 8 * 8
     out = torch.empty((n, cout, out_h, out_w), dtype=torch.float32, device=input.device)
@@ -85,13 +101,101 @@ def _run(input, weight, bias, stride, padding, dilation, groups, transposed, out
         og = out if groups == 1 else torch.empty((n, cout_g, out_h, out_w), dtype=torch.float32,
                                                  device=input.device)
         K.conv2d(src0=x_nhwc, c0=cpad, ld0=cpad, n=n, h=h, w=w, out_h=out_h, out_w=out_w, weight=wp,
-                 cout=cout_g, kh=kh, kw=kw, stride=stride, pad=pad_eff, dil=dilation,
+                 cout=cout_g, kh=kh, kw=kw, stride=stride, pad=padding, dil=dilation,
                  transposed=int(transposed), bias=(b32[g * cout_g:(g + 1) * cout_g].contiguous()
                                                    if b32 is not None else None),
                  out=og, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, dtype=K.dt_code(dtype))
         if groups > 1:
             out[:, g * cout_g:(g + 1) * cout_g] = og
     return out if dtype == torch.float32 else out.to(dtype)
+
+
+def _output_padding(cfg, input_shape, output_shape, weight_shape):
+    """output_padding of the opposite convolution that maps grad_output back to the input's size
+    (op/conv2d_gradfix.py:122-132)."""
+    transposed, stride, padding, _, dilation = cfg
+    if transposed:
+        return (0, 0)
+    return tuple(input_shape[i + 2] - (output_shape[i + 2] - 1) * stride - (1 - 2 * padding)
+                 - dilation * (weight_shape[i + 2] - 1) for i in range(2))
+
+
+def _grad_weight_kernel(inp, grad, kh, kw, stride, padding, dilation):
+    """dW[c_grad, c_inp, ky, kx] = sum_{n,oy,ox} grad[n,c_grad,oy,ox] * inp[n,c_inp,oy*s+ky*d-p,ox*s+kx*d-p]
+    as ONE forward contraction with the batch as the contraction axis."""
+    y = _launch(inp.transpose(0, 1).contiguous(), grad.transpose(0, 1).contiguous(), None, dilation, padding,
+                stride, 1, False, 0)
+    if y.shape[2] < kh or y.shape[3] < kw:
+        raise ValueError("conv2d_gradfix: inconsistent shapes in the weight gradient")
+    return y[:, :, :kh, :kw].transpose(0, 1).contiguous()
+
+
+class _Conv(torch.autograd.Function):
+    """groups == 1.  cfg = (transposed, stride, padding, output_padding, dilation)."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, cfg):
+        transposed, stride, padding, output_padding, dilation = cfg
+        ctx.cfg = cfg
+        ctx.save_for_backward(input, weight)
+        return _launch(input, weight, bias, stride, padding, dilation, 1, transposed, output_padding)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        transposed, stride, padding, _, dilation = ctx.cfg
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            p = _output_padding(ctx.cfg, input.shape, grad_output.shape, weight.shape)
+            grad_input = _Conv.apply(grad_output, weight, None, (not transposed, stride, padding, p, dilation))
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            grad_weight = _ConvGradWeight.apply(grad_output, input, ctx.cfg, tuple(weight.shape))
+        if ctx.needs_input_grad[2]:
+            grad_bias = grad_output.sum((0, 2, 3))
+        return grad_input, grad_weight, grad_bias, None
+
+
+class _ConvGradWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grad_output, input, cfg, weight_shape):
+        transposed, stride, padding, _, dilation = cfg
+        ctx.cfg, ctx.weight_shape = cfg, weight_shape
+        ctx.save_for_backward(grad_output, input)
+        kh, kw = weight_shape[2], weight_shape[3]
+        g, x = grad_output.detach(), input.detach()
+        if transposed:   # weight is (Cin, Cout, kh, kw): the roles of input and grad_output swap
+            return _grad_weight_kernel(g, x, kh, kw, stride, padding, dilation)
+        return _grad_weight_kernel(x, g, kh, kw, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, grad_grad_weight):
+        grad_output, input = ctx.saved_tensors
+        transposed, stride, padding, _, dilation = ctx.cfg
+        gg_output = gg_input = None
+        if ctx.needs_input_grad[0]:
+            gg_output = _Conv.apply(input, grad_grad_weight, None, ctx.cfg)
+        if ctx.needs_input_grad[1]:
+            p = _output_padding(ctx.cfg, input.shape, grad_output.shape, ctx.weight_shape)
+            gg_input = _Conv.apply(grad_output, grad_grad_weight, None, (not transposed, stride, padding, p, dilation))
+        return gg_output, gg_input, None, None
+
+
+def _run(input, weight, bias, stride, padding, dilation, groups, transposed, output_padding):
+    _check(input, weight)
+    needs_grad = torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or
+                                              (bias is not None and bias.requires_grad))
+    if not needs_grad:
+        return _launch(input, weight, bias, stride, padding, dilation, groups, transposed, output_padding)
+    stride, padding, dilation = _one(stride, "stride"), _one(padding, "padding"), _one(dilation, "dilation")
+    cfg = (bool(transposed), stride, padding, _pair(output_padding, "output_padding"), dilation)
+    if groups == 1:
+        return _Conv.apply(input, weight, bias, cfg)
+    # grouped convolution (ModulatedConv2d folds the batch into groups, model.py:273-304): one
+    # differentiable launch per group; the slicing / concatenation is data movement only
+    xs = input.chunk(groups, dim=1)
+    ws = weight.chunk(groups, dim=0)
+    bs = bias.chunk(groups, dim=0) if bias is not None else [None] * groups
+    return torch.cat([_Conv.apply(x.contiguous(), w.contiguous(), b, cfg) for x, w, b in zip(xs, ws, bs)], dim=1)
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
