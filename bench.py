@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("VT_BENCH_LANES", "3")),
                     help="frames in flight per GPU: step i runs on HIP stream i %% lanes with its own plan buffers")
+    ap.add_argument("--tile-hints", default=os.environ.get("VT_TILE_HINTS", ""),
+                    help="JSON table {conv geometry: tile_hint} from tools/plan_sweep.py (default: built-in heuristics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the PCIe-inclusive video-driver measurement")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
@@ -190,7 +192,11 @@ def main():
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     del sd
-    eng = VToonifyEngine(sd_dev, args.backbone, 256, dtype, dev)
+    hints = None
+    if args.tile_hints:
+        with open(args.tile_hints) as f:
+            hints = {k: int(v) for k, v in json.load(f).items()}
+    eng = VToonifyEngine(sd_dev, args.backbone, 256, dtype, dev, tile_hints=hints)
     use_graph = not args.no_graph
 
     # ---- this rank's shard of the synthetic video, resident in HBM -------------------------
@@ -306,7 +312,7 @@ def main():
                                    f"seeded synthetic weights, style path recomputed every frame",
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{ws}",
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "frames_in_flight_per_gpu": lanes,
+                       "frames_in_flight_per_gpu": lanes, "tile_hints": args.tile_hints or None,
                        "splitk_workgroup_target": int(os.environ.get("VT_SPLITK_WGS", "256")),
                        "weight_broadcast_s": t_bcast},
             "roofline": roofline,

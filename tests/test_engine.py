@@ -197,3 +197,46 @@ def test_lanes_are_independent_plans(dev):
     assert torch.equal(y0, y1)
     p0, p1 = eng.plan_for(1, x.shape[2], x.shape[3], True, False), eng._plans[(1, x.shape[2], x.shape[3], True, False, 1)]
     assert p0 is not p1 and p0.bufs["x_nhwc"].data_ptr() != p1.bufs["x_nhwc"].data_ptr()
+
+
+def test_tile_hints_override_plans_per_geometry(dev):
+    """VToonifyEngine(tile_hints={signature: tile_hint}) (the table tools/plan_sweep.py writes): the hinted
+    kernel instance runs, results stay within tolerance, an uncompiled tile is rejected loudly."""
+    from vtoonify_amd import _lib
+    d, _ = load_golden("e2e_T.npz")
+    sd = synth.synth_state_dict(load_keys("T"), 0)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    eng = VToonifyEngine(sdd, "toonify", 256, torch.float32, dev)
+    y0 = eng.forward(x, s, 0.5)
+    plan = eng.plan_for(1, x.shape[2], x.shape[3], True, False)
+    sigs = {}
+    for dsc, info, _, _ in plan.convs:
+        sigs.setdefault(info["sig"], info["kernel"])
+    # every 3x3 stride-1 geometry onto the 1-D direct-to-LDS / register-staged 64x64 tile with 2 K-slices
+    hints = {sg: 2 * 100000000 + 2 * 1000000 + 64064 for sg in sigs if ":k3s1d1p1" in sg and not sg.endswith("nchw")}
+    assert len(hints) >= 5
+    eng2 = VToonifyEngine(sdd, "toonify", 256, torch.float32, dev, tile_hints=hints)
+    y1 = eng2.forward(x, s, 0.5)
+    plan2 = eng2.plan_for(1, x.shape[2], x.shape[3], True, False)
+    changed = [info for _, info, _, _ in plan2.convs if info["sig"] in hints]
+    assert changed and all("64x64" in info["kernel"] and "patch" not in info["kernel"] for info in changed)
+    check(y1, d["y_ds0.5"], torch.float32, "hinted plans")
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
+    bad = dict(hints)
+    bad[next(iter(hints))] = 100000000 + 96096     # no such compiled patch tile
+    with pytest.raises(_lib.VtError):
+        VToonifyEngine(sdd, "toonify", 256, torch.float32, dev, tile_hints=bad).forward(x, s, 0.5)
+
+
+def test_plan_sweep_candidates_are_wellformed():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "plan_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "plan_sweep.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    c = ps.candidates("32x32:512->512:k3s1d4p1")
+    assert c and all((h // 100000000) in (1, 2) for h in c) and 100000000 + 8 * 1000000 + 128128 in c
+    assert all(h % 1000 <= 32 for h in ps.candidates("256x256:136->3:k3s1d1p1:nchw"))
+    assert all(h // 100000000 == 2 for h in ps.candidates("64x64:512->512:k3s2d1p1"))

@@ -65,7 +65,8 @@ class VToonifyEngine:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "dualstylegan",
                  in_size: int = 256, dtype: torch.dtype = torch.bfloat16,
-                 device: Optional[torch.device] = None, cache_styles: bool = False):
+                 device: Optional[torch.device] = None, cache_styles: bool = False,
+                 tile_hints: Optional[Dict[str, int]] = None):
         assert backbone in ("dualstylegan", "toonify")
         assert dtype in (torch.bfloat16, torch.float32)
         self.backbone = backbone
@@ -81,6 +82,14 @@ class VToonifyEngine:
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
         self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
+        # per-layer plan overrides {conv_signature(desc): vt_conv_desc.tile_hint}: lets a measured table
+        # (tools/plan_sweep.py) pick tile / split-K / kernel family per conv geometry without a rebuild.
+        # Like the built-in heuristics the key never contains the batch, so frames stay batch-invariant.
+        self.tile_hints: Dict[str, int] = dict(tile_hints or {})
+        if not self.tile_hints and os.environ.get("VT_TILE_HINTS"):
+            import json
+            with open(os.environ["VT_TILE_HINTS"]) as f:
+                self.tile_hints = {k: int(v) for k, v in json.load(f).items()}
         self._style_key = None
         self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.g = "generator.generator." if self.dual else "generator."
@@ -136,13 +145,25 @@ class VToonifyEngine:
         plan.bufs[name] = t
         return t
 
+    @staticmethod
+    def conv_signature(d) -> str:
+        """Geometry key of a conv launch (no batch): 'HxW:cin->cout_total:k3s1d1p1[:nchw]'."""
+        return (f"{d.h}x{d.w}:{d.c0 + d.c1}->{d.cout * d.phases}:k{d.kh}s{d.stride}d{d.dil}p{d.phases}"
+                + (":nchw" if d.out_layout == OUT_NCHW else ""))
+
+    def _apply_hint(self, d):
+        h = self.tile_hints.get(self.conv_signature(d))
+        if h:
+            d.tile_hint = int(h)
+        return d
+
     def _op_conv(self, ops, plan, ref_macs=None, **kw):
         """Append one vt_conv2d launch.  The op's info records the kernel instance (tile) and
         its ALGORITHMIC work: flops = 2 x the MACs of the reference contraction it replaces
         (`ref_macs` overrides that for the fused conv_transpose2d+blur form, whose polyphase
         filters do 4x the transposed conv's MACs), bytes = every operand read once + the
         output written once."""
-        d = K.make_conv_desc(dtype=self.dt, **kw)
+        d = self._apply_hint(K.make_conv_desc(dtype=self.dt, **kw))
         plan.keep.append(d)
         cin = d.c0 + d.c1
         m = d.n * d.out_h * d.out_w
@@ -152,7 +173,8 @@ class VToonifyEngine:
         nbytes = (d.n * d.h * d.w * cin * self.esz + cout_t * d.kh * d.kw * cin * self.esz +
                   m * cout_t * osz * (2 if d.resid else 1))
         info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
-                "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w)}
+                "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w),
+                "sig": self.conv_signature(d)}
         plan.convs.append((d, info, ops, len(ops)))
         ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
@@ -491,7 +513,7 @@ class VToonifyEngine:
                 rgb_kw = dict(rgb_weight=wm3, rgb_bias=self.w[f"{n3}.bias"], rgb_resid=rgb_ptr, rgb_out=rgb_ptr)
                 # ToRGB (1x1 modulated conv, no demod, + bias + up-sampled skip; model.py:383-392) is
                 # fused into the StyledConv's epilogue when one tile holds all its channels
-                probe = K.make_conv_desc(dtype=self.dt, **same_kw, **rgb_kw)
+                probe = self._apply_hint(K.make_conv_desc(dtype=self.dt, **same_kw, **rgb_kw))
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
