@@ -107,6 +107,10 @@ def test_style_cache_and_determinism(dev):
         assert torch.equal(y1, y0) and torch.equal(y2, y0)
         y3 = eng.forward(x, s, 1.0)   # key change -> recomputed
         assert not torch.equal(y3, y0)
+        # the cache is per plan: lanes that alternate frame by frame each keep theirs
+        for lane in (1, 0, 1, 0):
+            assert torch.equal(eng.forward(x, s, 0.5, lane=lane), y0), lane
+        assert eng._plans[(1, x.shape[2], x.shape[3], True, True, 1)].style_key is not None
     finally:
         eng.cache_styles = False
     # shared-style batch == per-frame calls (video path: s_w.repeat(B,1,1), style_transfer.py:176)

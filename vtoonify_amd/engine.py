@@ -90,7 +90,6 @@ class VToonifyEngine:
             import json
             with open(os.environ["VT_TILE_HINTS"]) as f:
                 self.tile_hints = {k: int(v) for k, v in json.load(f).items()}
-        self._style_key = None
         self.sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.g = "generator.generator." if self.dual else "generator."
         self.n_down = 0
@@ -626,15 +625,17 @@ class VToonifyEngine:
             raise _lib.VtError(f"expected {plan.cin0} input channels, got {cin}")
         # ---- per-call inputs into the plan's static buffers ---------------------------
         srows = style[:1] if shared_style else style
-        skey = (id(plan), srows.data_ptr(), getattr(srows, "_version", 0), d_s, wspace)
-        need_style = not (self.cache_styles and skey == self._style_key)
+        # the style products (modulated weights, AdaIN gamma/beta) live in the plan's own buffers, so the
+        # cache key is per plan: lanes that alternate frame by frame each keep their cache warm
+        skey = (srows.data_ptr(), getattr(srows, "_version", 0), d_s, wspace)
+        need_style = not (self.cache_styles and skey == getattr(plan, "style_key", None))
         if "x_in" not in plan.bufs:
             self._buf(plan, "x_in", (B, cin, H, W), torch.float32)
         plan.bufs["x_in"].copy_(x.detach())
         if need_style:
             plan.bufs["style_in"].copy_(srows)
             plan.bufs["d_s"].fill_(d_s)
-            self._style_key = skey if self.cache_styles else None
+            plan.style_key = skey if self.cache_styles else None
         if use_graph and self.device.type == "cuda" and not return_feat:
             self._replay(plan, need_style)
         else:
