@@ -314,6 +314,21 @@ int vt_resize_bilinear(void* out, int out_layout, int ld_out, int out_dtype, con
                        int c, int h, int w, int virt_h, int virt_w, int align_corners, int step,
                        int out_h, int out_w, float mul, vt_stream stream);
 
+/* ---------------------------------------------------------------------------------
+ * RAFT correlation lookup -- replaces alt_cuda_corr.forward (model/raft/alt_cuda_corr/correlation.cpp:24-34,
+ * correlation_kernel.cu:19-120; caller AlternateCorrBlock, model/raft/core/corr.py:63-91).  fp32.
+ *   fmap1 (batch,h1,w1,c), fmap2 (batch,h2,w2,c) NHWC contiguous; coords (batch,1,h1,w1,2) = (x, y)
+ *   target positions in fmap2; corr (batch,1,(2r+1)^2,h1,w1):
+ *     corr[b,0,a+(2r+1)*k,p] = scale * bilinear_{(y-r+a, x-r+k)} <fmap1[b,p,:], fmap2[b,.,.,:]>, zero outside
+ *   evaluated at coords * coord_scale (the pyramid level's coords / 2**i, corr.py:84) (the reference applies the
+ *   1/sqrt(c) afterwards, corr.py:91: scale = 1, coord_scale = 1 give alt_cuda_corr.forward's exact output).
+ *   vt_avgpool2x2: F.avg_pool2d(x, 2, stride=2) on NHWC fp32 (the feature pyramid, corr.py:68-71).
+ * --------------------------------------------------------------------------------- */
+int vt_corr_lookup(float* corr, const float* fmap1, const float* fmap2, const float* coords, int batch,
+                   int h1, int w1, int h2, int w2, int c, int radius, float scale, float coord_scale,
+                   vt_stream stream);
+int vt_avgpool2x2(float* out, const float* x, int n, int h, int w, int c, vt_stream stream);
+
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,
                     int in_dtype, int out_dtype, vt_stream stream);

@@ -109,6 +109,8 @@ _SIGS = {
     "vt_gate_add_nearest": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "vt_resize_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 10 +
                            [C.c_float, C.c_void_p]),
+    "vt_corr_lookup": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_void_p]),
+    "vt_avgpool2x2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
