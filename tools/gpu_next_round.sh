@@ -14,6 +14,9 @@ run small_lds VT_SMALL_LDS=1
 run occ2 VT_PATCH_OCC2=1
 run small_lds_occ2 VT_SMALL_LDS=1 VT_PATCH_OCC2=1
 run wg128 VT_SPLITK_WGS=128
+run small_lds_l4 VT_SMALL_LDS=1 VT_PATCH_OCC2=1 VT_BENCH_LANES=4
+run hwq8_l4 GPU_MAX_HW_QUEUES=8 VT_BENCH_LANES=4
+run hwq8_l6 GPU_MAX_HW_QUEUES=8 VT_BENCH_LANES=6
 run base2 A=1
 timeout 700 python tools/plan_sweep.py --lanes 3 --top 14 --budget-s 600 --out gpurun_out/tile_hints_$TAG.json > gpurun_out/plan_sweep_$TAG.log 2>&1; grep -v "^W\|^E" gpurun_out/plan_sweep_$TAG.log | tail -25
 [ -s gpurun_out/tile_hints_$TAG.json ] && run hinted VT_TILE_HINTS=$GRAFT_REPO_ROOT/gpurun_out/tile_hints_$TAG.json
