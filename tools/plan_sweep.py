@@ -57,51 +57,67 @@ def candidates(sig):
 
 
 class Rig:
-    def __init__(self, lanes, steps, backbone, H, W):
+    def __init__(self, lanes, steps, backbone, H, W, emu=False):
         from vtoonify_amd import _lib, synth
         from vtoonify_amd.engine import VToonifyEngine
-        _lib.use_library(_lib.DEFAULT_LIB)
-        self.dev = torch.device("cuda:0")
+        self.emu = emu
+        if emu:   # control-flow dry run on the host emulation of the kernels (no timing meaning)
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            from emu import build_emu
+            _lib.use_library(build_emu.build())
+            self.dev = torch.device("cpu")
+        else:
+            _lib.use_library(_lib.DEFAULT_LIB)
+            self.dev = torch.device("cuda:0")
         tag = "D" if backbone == "dualstylegan" else "T"
         sd = synth.synth_state_dict(keys(tag), 0)
-        self.eng = VToonifyEngine({k: v.to(self.dev) for k, v in sd.items()}, backbone, 256, torch.bfloat16, self.dev)
+        self.eng = VToonifyEngine({k: v.to(self.dev) for k, v in sd.items()}, backbone, 256,
+                                  torch.float32 if emu else torch.bfloat16, self.dev)
         self.style = synth.synth_style(seed=17).to(self.dev)
         self.pool = [synth.synth_frames(1, H, W, seed=i).to(self.dev) for i in range(4)]
         self.lanes, self.steps = lanes, steps
-        self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(lanes - 1)]
+        self.streams = None if emu else ([torch.cuda.current_stream(self.dev)] +
+                                         [torch.cuda.Stream(self.dev) for _ in range(lanes - 1)])
 
     def set_hints(self, hints):
         self.eng.tile_hints = dict(hints)
         self.eng._plans.clear()          # plans (buffers, graphs) are rebuilt with the new table
-        torch.cuda.empty_cache()
+        if not self.emu:
+            torch.cuda.empty_cache()
 
     def step(self, i):
         ln = i % self.lanes
+        if self.emu:
+            return self.eng.forward(self.pool[i % 4], self.style, 0.5, shared_style=True, lane=ln)
         with torch.cuda.stream(self.streams[ln]):
             return self.eng.forward(self.pool[i % 4], self.style, 0.5, shared_style=True, use_graph=True, lane=ln)
 
     def fps(self, repeats=3):
+        sync = (lambda: None) if self.emu else torch.cuda.synchronize
         for i in range(self.lanes):
             y = self.step(i)
-            torch.cuda.synchronize()
-        for i in range(2 * self.lanes):
+            sync()
+        for i in range(0 if self.emu else 2 * self.lanes):
             self.step(i)
-        torch.cuda.synchronize()
+        sync()
         best = 0.0
         for _ in range(repeats):
             t0 = time.perf_counter()
             for i in range(self.steps):
                 self.step(i)
-            torch.cuda.synchronize()
+            sync()
             best = max(best, self.steps / (time.perf_counter() - t0))
         return best, y
 
     def shares(self):
         """conv geometries of the frame with their share of the single-stream kernel time."""
         self.step(0)
-        torch.cuda.synchronize()
         plan = self.eng.plan_for(1, self.pool[0].shape[2], self.pool[0].shape[3], True, True)
-        per = self.eng.time_ops(plan, iters=3)
+        if self.emu:   # no HIP events on the host: rank by algorithmic flops instead
+            per = [(self.eng._info(op[2]), 1e-12 * self.eng._info(op[2]).get("flops", 0)) for op in self.eng.frame_ops(plan)]
+        else:
+            torch.cuda.synchronize()
+            per = self.eng.time_ops(plan, iters=3)
         agg = {}
         for info, ms in per:
             if info.get("name") == "conv":
@@ -123,9 +139,11 @@ def main():
     ap.add_argument("--budget-s", type=float, default=600.0)
     ap.add_argument("--backbone", default="dualstylegan")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--emu", action="store_true", help="dry run of the search loop on the CPU emulation (tiny frames)")
+    ap.add_argument("--size", type=int, default=256, help="input height = width")
     a = ap.parse_args()
     t_start = time.perf_counter()
-    rig = Rig(a.lanes, a.steps, a.backbone, 256, 256)
+    rig = Rig(a.lanes, a.steps, a.backbone, a.size, a.size, emu=a.emu)
     rig.set_hints({})
     base, y0 = rig.fps()
     y0 = y0.clone()
