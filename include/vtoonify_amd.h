@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 1
+#define VT_ABI_VERSION 2
 
 enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
@@ -154,10 +154,14 @@ typedef struct vt_conv_desc {
                               Consumer: vt_instnorm_apply_stats. */
     int32_t post_relu;     /* != 0: out = max(v + beta * resid, 0) -- the ReLU that FOLLOWS the shortcut add
                               of a ResNet BasicBlock (model/bisenet/resnet.py:36-48); 0 = off */
+    const void* weight_stream; /* NULL, or the vt_conv_weight_stream image of `weight` (same values in MFMA-fragment
+                              order).  Enables the whole-K kernel for 3x3 stride-1 pad == dil convs whose channel
+                              count is a multiple of 512 (bf16) / 256 (fp32): few-pixel, wide-channel layers run
+                              without split-K slabs and without a reduce pass (KIND 4 of vt_conv2d_tile) */
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
-/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel; -1: invalid descriptor).
+/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel, 4 whole-K kernel; -1: invalid descriptor).
  * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
 int vt_conv2d_tile(const vt_conv_desc* desc);
 /* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */
@@ -171,6 +175,16 @@ int64_t vt_conv2d_ws_bytes(const vt_conv_desc* desc);
 int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_src, int kh, int kw,
                         int cin_dst, const int32_t* chan_map, float scale,
                         int src_transposed, int out_dtype, vt_stream stream);
+
+/* Fragment-stream image of packed weights for the whole-K kernel (vt_conv_desc.weight_stream):
+ *   packed [cout][taps][cin] (vt_pack_conv_weight layout, dtype VT_F32 / VT_BF16, cin a multiple of the
+ *   128-byte K-step: 64 bf16 / 32 fp32)  ->  [ceil(cout/32)][cin/BK][taps][2][2][64 lanes] x 16 bytes,
+ * i.e. for every (32-channel tile, channel chunk, tap, half chunk, 16-row fragment) the 1 KB a wavefront
+ * feeds to the MFMA as its weight operand, in lane order; rows beyond cout are zero.
+ * vt_conv_weight_stream_bytes gives the size of `out` (> 0) or -1 for unsupported shapes. */
+int64_t vt_conv_weight_stream_bytes(int cout, int taps, int cin, int dtype);
+int vt_conv_weight_stream(void* out, const void* packed, int cout, int taps, int cin, int dtype,
+                          vt_stream stream);
 
 /* ModulatedConv2d weight path (model/stylegan/model.py:259-267):
  *   w'[co,ci,a,b] = scale * weight[co,ci,a,b] * s[ci];  demod: w' *= rsqrt(sum w'^2 + 1e-8)

@@ -26,8 +26,8 @@ def build(force=False):
     from vtoonify_amd.build import SOURCES
     os.makedirs(OUT, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "hip_emu.cpp")]
-    deps = srcs + [os.path.join(HERE, "hip_emu.hpp"), os.path.join(CSRC, "vt_common.hpp"),
-                   os.path.join(REPO, "include", "vtoonify_amd.h")]
+    deps = srcs + [os.path.join(HERE, "hip_emu.hpp"), os.path.join(REPO, "include", "vtoonify_amd.h")] + \
+        [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     objs = []

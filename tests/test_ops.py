@@ -602,3 +602,78 @@ def test_conv_patch_small_tile_whole_k(dev, dtype):
             hint = P + s * 1000000 + 64064
             assert _conv_case(dev, dtype, 2, 192, 9, 21, 136, 3, 1, dil, dil, act=L, hint=hint, resid=True, ws=True,
                               seed=dil * 10 + s, expect_kind=1) < t, (dil, s)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_whole_k_kernel(dev, dtype):
+    """conv_fullk_kernel (vt_conv_desc.weight_stream): K split across the 8 wavefronts of a workgroup and
+    summed through LDS -- no split-K slabs.  Covers one and two rounds of 8 channel chunks, two concat
+    sources, dilation 1/2/4 (strided tiles), odd image sizes (partial tiles), a cout tail inside the last
+    32-channel tile, batch, the residual / activation epilogue and planar output; compared with the oracle on
+    the same rounded operands, and with the slab path on the same inputs."""
+    import ctypes
+    from vtoonify_amd import _lib
+    g = np.random.default_rng(77)
+    t = F32_TOL if dtype == torch.float32 else 8e-3
+    unit = 256 if dtype == torch.float32 else 512          # 8 wavefronts x one 128-byte row of channels
+    L = K.ACT_LRELU
+    cases = [  # (N, c0, c1, H, W, Cout, dil, act, resid, planar)
+        (1, unit, 0, 8, 8, 32, 1, L, False, False),
+        (2, unit, 0, 9, 11, 136, 1, L, True, False),            # cout >= 128: chosen without a hint
+        (1, unit, 0, 9, 11, 40, 2, 0, True, False),
+        (2, unit, 0, 5, 13, 64, 4, L, False, False),
+        (1, 2 * unit, 0, 7, 9, 32, 1, L, True, False),          # two rounds
+        (1, unit, unit, 6, 10, 40, 1, 0, False, False),         # two sources (torch.cat of Fusion)
+        (1, unit, 0, 10, 9, 8, 1, K.ACT_RELU_TANH, False, True),  # planar fp32 output
+    ]
+    for N, c0, c1, H, W, Cout, dil, act, resid, planar in cases:
+        cin = c0 + c1
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((Cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(Cout).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        wst = K.conv_weight_stream(wp)
+        assert wst is not None
+        xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(Cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        ref = O.conv2d(xq, wq, b, 1, dil, dil)
+        gain = 1.0
+        if act == L:
+            ref, gain = O.leaky_relu(ref, 0.2) * np.float32(2 ** 0.5), 2 ** 0.5
+        elif act == K.ACT_RELU_TANH:
+            ref = np.tanh(np.maximum(ref, 0))
+        if c1:   # the second source lives in its own tensor with a larger pixel stride
+            x0 = xt[..., :c0].contiguous()
+            x1 = torch.zeros((N, H, W, c1 + 16), dtype=dtype, device=dev)
+            x1[..., :c1] = xt[..., c0:]
+            srcs = dict(src0=x0, c0=c0, ld0=c0, src1=x1, c1=c1, ld1=c1 + 16)
+        else:
+            srcs = dict(src0=xt, c0=c0, ld0=c0)
+        common = dict(n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=Cout, kh=3, kw=3, pad=dil, dil=dil,
+                      bias=T(b, dev), act=act, gain=gain, dtype=K.dt_code(dtype), alpha=0.5 if resid else 1.0,
+                      beta=0.25 if resid else 0.0, **srcs)
+        outs = []
+        for stream in (wst, None):
+            if planar:
+                out = torch.zeros((N, Cout, H, W), dtype=torch.float32, device=dev)
+                kw = dict(out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32)
+                r = None
+            else:
+                out = torch.zeros((N, H, W, Cout), dtype=dtype, device=dev)
+                r = None
+                if resid:
+                    rn = np.random.default_rng(5).standard_normal((N, Cout, H, W)).astype(np.float32)
+                    r = K.nchw_to_nhwc(T(rn, dev), dtype, ld_out=Cout)
+                kw = dict(out=out, ld_out=Cout, resid=r, ld_res=Cout)
+            hint = 4 * P if (stream is not None and Cout < 128) else 0   # small cout: forced by hint
+            d = K.make_conv_desc(weight_stream=stream, tile_hint=hint, **kw, **common)
+            code = _lib.lib().vt_conv2d_tile(ctypes.byref(d))
+            assert (code // 100000000 == 4) == (stream is not None), code
+            K.conv2d(weight_stream=stream, tile_hint=hint, **kw, **common)
+            outs.append(out.float().cpu().numpy() if planar else out.float().cpu().permute(0, 3, 1, 2).numpy())
+        want = ref
+        if resid and not planar:
+            want = ref * 0.5 + 0.25 * r.float().cpu().permute(0, 3, 1, 2).numpy()
+        assert rel_err(outs[0], want) < t, (N, c0, c1, H, W, Cout, dil)
+        assert rel_err(outs[0], outs[1]) < t, "whole-K kernel vs the slab path"

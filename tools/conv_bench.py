@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--nosplit", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the register-staged loader")
     ap.add_argument("--nopatch", action="store_true", help="disable the patch-resident kernel")
+    ap.add_argument("--stream", action="store_true",
+                    help="attach the fragment-stream weights (whole-K kernel where eligible; add --hint 400000000 to force it)")
     ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
     args = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
@@ -90,6 +92,11 @@ def main():
         d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout,
                              kh=k, kw=k, stride=stride, pad=pad, dil=dil, phases=phases, bias=bias,
                              act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint + (1000000000 if args.generic else 0) + (200000000 if args.nopatch else 0), **kw)
+        wst = None
+        if args.stream and k == 3 and phases == 1:
+            wst = K.conv_weight_stream(wt)
+            if wst is not None:
+                d.weight_stream = wst.data_ptr()
         if args.rgb and name.startswith("same") and lay == "nhwc" and cout <= 128:
             rgbw = (torch.randn(3, 1, cout, device=dev) / cout ** 0.5).to(dt)
             rgbb = torch.randn(3, device=dev)

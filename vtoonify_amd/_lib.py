@@ -15,6 +15,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
+ABI_VERSION = 2   # VT_ABI_VERSION of include/vtoonify_amd.h
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_NCHW = 0, 1
@@ -50,6 +51,7 @@ class ConvDesc(C.Structure):
         ("splitk_phase", C.c_int32),
         ("stats_part", C.c_void_p),
         ("post_relu", C.c_int32),
+        ("weight_stream", C.c_void_p),
     ]
 
 
@@ -78,6 +80,8 @@ _SIGS = {
     "vt_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "vt_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "vt_conv2d_ws_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "vt_conv_weight_stream_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vt_conv_weight_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "vt_modulate_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -137,8 +141,8 @@ def _bind(path: str):
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vt_abi_version() != 1:
-        raise VtError(f"{path}: ABI version {lib.vt_abi_version()} != 1")
+    if lib.vt_abi_version() != ABI_VERSION:
+        raise VtError(f"{path}: ABI version {lib.vt_abi_version()} != {ABI_VERSION}")
     return lib
 
 

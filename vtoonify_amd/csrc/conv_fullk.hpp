@@ -1,0 +1,261 @@
+// Whole-K 3x3 convolution for the small-plane, wide-channel layers -- the 32x32-pixel trunk of the
+// frame (encoder.4.* VToonifyResBlocks, model/vtoonify.py:92-104,235-239; the AdaResBlocks of
+// model/dualstylegan.py:38-45; the Fusion conv, vtoonify.py:125-127).  Included by conv_igemm.hip
+// inside its anonymous namespace (shares ConvArgs, Mma<T>, conv_finish, store_out4, decode_block).
+//
+// Why another kernel: these layers are M = 1024 pixels x N = 512 channels x K = 4608 (4.8 GFLOP,
+// 1.9 us of MFMA on 256 CUs).  The patch kernel fills the chip by cutting K into 8 slices per
+// 128x128 tile; every slice writes a 64 KB fp32 slab (16.8 MB per conv) that a second kernel
+// re-reads -- 4.6-6.7x the algorithmic HBM bytes and a second launch per conv (round-1 PMC).
+// Here K is split ACROSS THE 8 WAVEFRONTS OF ONE WORKGROUP instead and summed through LDS:
+//
+//   * workgroup = 8x8 output pixels x 32 output channels, 512 threads; 1024 x 512 outputs = 256
+//     workgroups = one per CU, no split-K workspace, no reduce pass, bf16 written once;
+//   * wavefront w owns the input channels [w*BK, (w+1)*BK) of every round of 8*BK channels
+//     (BK = 64 bf16 / 32 fp32 = one 128-byte LDS row) and computes the whole 64x32 tile over them:
+//     its 10x10-pixel input patch chunk is fetched ONCE into a wave-private LDS region
+//     (buffer_load ... lds, zero fill = the conv's zero padding) and serves all 9 taps;
+//   * the weights are read exactly once per workgroup and used by one wave only, so they never
+//     touch LDS: they stream from L2 straight into VGPRs, pre-packed in MFMA-fragment order
+//     (vt_conv_weight_stream: one wave-instruction = one fully coalesced 1 KB line), DEPTH
+//     sub-steps ahead;
+//   * no workgroup barrier in the main loop (nothing is shared between waves until the end);
+//     the 8 partial tiles are exchanged through the (now idle) patch regions and summed in wave
+//     order 0..7 -- deterministic;
+//   * dilation d is d*d interleaved dense problems: a tile takes every d-th pixel of one phase
+//     (y % d, x % d), so the patch is 10x10 pixels for every dilation (a dense 8x8 tile at d = 4
+//     would need a 16x16 patch); only the address arithmetic knows about d.
+//
+// LDS image of a patch chunk: row r = py*10 + px (128 B = BK channels), 16-byte slot s stored at
+// slot s ^ 2*((px >> 1) & 3).  An A fragment is 16 pixels = two 8-pixel tile rows; with that XOR
+// every ds_read_b128 lane group of gfx950 ({0-3,12-15,20-27}, ...) hits 16 distinct slots of the
+// 256-byte bank row for every tap (checked exhaustively, tools/lds_bank_check.py).
+#pragma once
+
+struct FullkArgs {
+    uint32_t nrec0, nrec1;    // byte sizes of the two sources (buffer range check = zero padding)
+    const void* wstream;      // vt_conv_weight_stream image of the weights
+    int rounds;               // cin / (8 * BK)
+    int tiles_y, tiles_x;     // 8x8-pixel tiles per dilation phase
+};
+
+constexpr int FK_TH = 8, FK_TW = 8, FK_BN = 32, FK_NW = 8;
+constexpr int FK_PW = FK_TW + 2, FK_PH = FK_TH + 2, FK_PROWS = FK_PW * FK_PH;   // 10 x 10 patch
+constexpr int FK_PA = (FK_PROWS + 7) / 8;                                      // 13 loads of 8 rows
+constexpr int FK_ABYTES = FK_PA * 1024;                                        // 13 KB per wave
+constexpr int FK_DEPTH = 6;                                                    // weight sub-steps in flight (static_assert AHEAD ladder below)
+
+__device__ __forceinline__ int fk_swz(int px) { return ((px >> 1) & 3) << 1; }
+
+template <typename T>
+__global__ void __launch_bounds__(FK_NW * 64)
+conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VEC = 16 / ESZ;
+    constexpr int BK = 8 * VEC;                 // channels per 128-byte row
+    constexpr int NSUB = 18;                    // sub-steps per chunk: 9 taps x 2 half rows
+    static_assert(NSUB % FK_DEPTH == 0, "static ring slots");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[FK_NW * FK_ABYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (FK_NW - 1);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int hi = l15 >> 3, lo = l15 & 7;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
+    const int d = p.dil;
+    // tile_m -> (image, phase_y, phase_x, tile_y, tile_x)
+    const int per_phase = g.tiles_y * g.tiles_x;
+    const int per_img = per_phase * d * d;
+    const int img = tile_m / per_img;
+    int rem = tile_m - img * per_img;
+    const int ph = rem / per_phase;
+    rem -= ph * per_phase;
+    const int fy = ph / d, fx = ph - fy * d;
+    const int ty0 = rem / g.tiles_x, tx0 = rem - ty0 * g.tiles_x;
+    const int y0 = fy + ty0 * FK_TH * d, x0 = fx + tx0 * FK_TW * d;   // image position of tile pixel (0, 0)
+    const int n0 = tile_n * FK_BN;
+
+    unsigned char* my = smem + wave * FK_ABYTES;
+    const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
+    const BufRsrc r1 = vt_make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? g.nrec1 : 0u);
+    const int nchunks = p.cin / BK;
+
+    // patch chunk of round r -> this wave's LDS region (13 wave-loads of 8 rows x 128 B)
+    auto issue_patch = [&](int r) {
+        const int kc = (r * FK_NW + wave) * BK;
+        const bool s1 = kc >= p.c0;
+        const uint32_t so = (uint32_t)((s1 ? kc - p.c0 : kc) * ESZ);
+        const uint32_t ldb = (uint32_t)((s1 ? p.ld1 : p.ld0) * ESZ);
+#pragma unroll
+        for (int i = 0; i < FK_PA; ++i) {
+            const int row = i * 8 + (lane >> 3);
+            const int py = row / FK_PW, px = row - py * FK_PW;
+            const int iy = y0 + (py - 1) * d, ix = x0 + (px - 1) * d;
+            const bool in = row < FK_PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
+            const uint32_t off = in ? pix * ldb + (uint32_t)((((lane & 7) ^ fk_swz(px))) << 4) : GLDS_OOB;
+            if (s1) vt_glds16(r1, my + i * 1024, off, so);
+            else vt_glds16(r0, my + i * 1024, off, so);
+        }
+    };
+    // weight stream: [tile_n][chunk][tap][half][fragment b][lane] x 16 B; the wave-uniform base goes through
+    // SGPRs, the lane offset is fixed
+    const uint32_t wlane = (uint32_t)lane * 16;
+    auto wround = [&](int r) -> const unsigned char* {
+        return (const unsigned char*)g.wstream + (size_t)((tile_n * nchunks + r * FK_NW + wave) * (NSUB * 2)) * 1024;
+    };
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS read bases: rows (hi, lo) of the fragment, one per (kx, half)
+    uint32_t abase[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+            abase[kx][sub] = (uint32_t)((hi * FK_PW + lo) * 128 + (((sub * 4 + q) ^ fk_swz(kx + lo)) << 4));
+    auto read_a = [&](u128 (&fa)[4], int st) {   // the four pixel fragments of sub-step st (compile-time st)
+        const int tap = st >> 1, sub = st & 1;
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = ld128(my + abase[kx][sub] + ((2 * a + ky) * FK_PW + kx) * 128);
+    };
+
+    // Every round starts like a prologue (patch + the first DEPTH weight sub-steps issued together, one memory
+    // latency) and drains its ring at the end: no register that a hidden load targets is live across the loop
+    // back-edge.  The trunk's 512-channel bf16 convs are a single round.
+    for (int r = 0; r < g.rounds; ++r) {
+        issue_patch(r);   // (r > 0: every ds_read of the previous round has been consumed by an MFMA)
+        const unsigned char* wcur = wround(r);
+        u128 wr[FK_DEPTH][2];
+#pragma unroll
+        for (int s = 0; s < FK_DEPTH; ++s) vt_gload16_pair_hidden(wr[s][0], wr[s][1], wcur + s * 2048, wlane);
+        vt_vmcnt_fence<0>();   // patch + first weights landed (the compiler's own wait for the LDS-DMA drains both anyway)
+        u128 fa[2][4];
+        read_a(fa[0], 0);
+#pragma unroll
+        for (int st = 0; st < NSUB; ++st) {
+            // loads issued after sub-step st's pair: the refills of the following min(DEPTH-1, NSUB-1-st) sub-steps
+            constexpr int AHEAD = FK_DEPTH - 1;
+            if (st >= FK_DEPTH) {
+                if (NSUB - 1 - st >= AHEAD) vt_vmcnt_fence<2 * AHEAD>();
+                else if (NSUB - 1 - st == 4) vt_vmcnt_fence<8>();
+                else if (NSUB - 1 - st == 3) vt_vmcnt_fence<6>();
+                else if (NSUB - 1 - st == 2) vt_vmcnt_fence<4>();
+                else if (NSUB - 1 - st == 1) vt_vmcnt_fence<2>();
+                else vt_vmcnt_fence<0>();
+            }
+            const u128 w0 = wr[st % FK_DEPTH][0], w1 = wr[st % FK_DEPTH][1];
+            if (st + FK_DEPTH < NSUB)
+                vt_gload16_pair_hidden(wr[st % FK_DEPTH][0], wr[st % FK_DEPTH][1], wcur + (st + FK_DEPTH) * 2048, wlane);
+            if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
+                Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
+            }
+        }
+    }
+    // ---- sum the 8 partial tiles through LDS (each wave parks its tile in its own patch region) ----
+    // scratch image: row = tile pixel (128 B = 32 fp32 channels), 16-byte slot s at s ^ (pixel & 7)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // fragment b of lane group q holds channels 8q + 4b .. +3 (weight rows are packed in that order)
+            const int px = a * 16 + l15;
+            float f[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            st128(my + px * 128 + (((2 * q + b) ^ (px & 7)) << 4), pack16<float>(f));
+        }
+    __syncthreads();
+    const int px = tid >> 3, c4 = tid & 7;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < FK_NW; ++w) {
+        float gv[4];
+        unpack16<float>(ld128(smem + w * FK_ABYTES + px * 128 + ((c4 ^ (px & 7)) << 4)), gv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] += gv[i];
+    }
+    const int oy = y0 + (px >> 3) * d, ox = x0 + (px & 7) * d;
+    const int n = n0 + 4 * c4;
+    if (oy >= p.H || ox >= p.W || n >= p.coutT) return;
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nn = n + i;
+        const float bv = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
+        f[i] = conv_finish(p, f[i], bv, ga, (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope);
+    }
+    store_out4(p, (img * p.H + oy) * p.W + ox, n, f);
+}
+
+// fragment-stream image of packed weights [cout][taps][cin] (vt_conv_weight_stream)
+template <typename T>
+__global__ void __launch_bounds__(256)
+weight_stream_kernel(T* __restrict__ out, const T* __restrict__ w, int cout, int taps, int cin, int64_t total16) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BK = 8 * VEC;
+    const int nchunks = cin / BK;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total16; v += (int64_t)gridDim.x * 256) {
+        // v = ((((tile_n * nchunks + chunk) * taps + tap) * 2 + sub) * 2 + b) * 64 + lane
+        const int lane = (int)(v & 63);
+        int64_t t = v >> 6;
+        const int b = (int)(t & 1); t >>= 1;
+        const int sub = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % taps); t /= taps;
+        const int chunk = (int)(t % nchunks);
+        const int tn = (int)(t / nchunks);
+        const int q = lane >> 4, l15 = lane & 15;
+        const int n = tn * FK_BN + 8 * (l15 >> 2) + 4 * b + (l15 & 3);
+        const int k = chunk * BK + sub * (BK / 2) + q * VEC;
+        u128 val = zero128();
+        if (n < cout) val = ld128(w + ((int64_t)n * taps + tap) * cin + k);
+        st128(out + v * VEC, val);
+    }
+}
+
+template <typename T>
+static bool fullk_eligible(const ConvArgs& a, const void* wstream, FullkArgs& g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BK = 8 * (16 / ESZ);
+    if (!wstream || a.force_generic || a.transposed || a.in_scale || a.rgb_w) return false;
+    if (a.taps != 9 || a.kw != 3 || a.stride != 1 || a.pad != a.dil || a.dil < 1 || a.dil > 8) return false;
+    if (a.Ho != a.H || a.Wo != a.W || a.phases != 1) return false;
+    if (a.cin % (FK_NW * BK) != 0 || a.c0 % BK != 0 || a.coutT % 8 != 0) return false;
+    const int64_t lim = ((int64_t)1 << 31) - 4096;
+    const int64_t px = (int64_t)a.N * a.H * a.W;
+    const int64_t n0 = px * a.ld0 * ESZ, n1 = px * a.ld1 * ESZ;
+    if (n0 >= lim || n1 >= lim) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrec1 = (uint32_t)n1;
+    g.wstream = wstream;
+    g.rounds = a.cin / (FK_NW * BK);
+    g.tiles_y = vt_cdiv(vt_cdiv(a.H, a.dil), FK_TH);
+    g.tiles_x = vt_cdiv(vt_cdiv(a.W, a.dil), FK_TW);
+    return true;
+}
+
+template <typename T>
+int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
+    ConvArgs args = a;
+    args.splitk = 1;
+    args.kps = 0;
+    args.slab_perm = 0;
+    args.tiles_n = vt_cdiv(a.coutT, FK_BN);
+    args.tiles_m = a.N * a.dil * a.dil * g.tiles_y * g.tiles_x;
+    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n;
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    auto k = conv_fullk_kernel<T>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    return vt_check_launch("vt_conv2d(fullk)");
+}

@@ -77,6 +77,7 @@ struct ConvArgs {
     int force_generic;  // tile_hint flag: run the register-staged kernel even when glds applies
     StatRec* stats_part;  // InstanceNorm chunk records of the output (vt_conv_desc.stats_part) or NULL
     int post_relu;      // vt_conv_desc.post_relu: max(., 0) after the residual add
+    const void* wstream;  // vt_conv_desc.weight_stream: fragment-stream image of the weights (whole-K kernel) or NULL
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -1277,6 +1278,8 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     }
 }
 
+#include "conv_fullk.hpp"
+
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
 __device__ __forceinline__ int slab_col4(const ConvArgs& p, int n) {
@@ -1580,7 +1583,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 //   P 2 (hint only) = never use the patch kernel;  S = split-K slices (0 = auto in a hint)
 // ---------------------------------------------------------------------------------------
 struct TilePlan {
-    int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel
+    int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp)
     int bm, bn, splitk;
 };
 
@@ -1654,9 +1657,33 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         t.splitk = 1;
         return t;
     }
-    const bool can_patch = hp != 2 && patch_eligible<T>(a, g);
+    {
+        // whole-K kernel (conv_fullk.hpp): the layers the heuristics below would cut along K into fp32 slabs --
+        // few pixels per image, wide channels.  Per-image geometry only (batch-invariant like every plan).
+        static const int fk_mode = [] {   // VT_FULLK_KERNEL=0 disables it (A/B), 2 = also where no split would happen
+            const char* e = getenv("VT_FULLK_KERNEL");
+            return e ? atoi(e) : 1;
+        }();
+        FullkArgs fg;
+        const bool hinted = hp == 4;
+        if (hp != 2 && (hbm == 0 || hinted) && (fk_mode > 0 || hinted) && fullk_eligible<T>(a, a.wstream, fg)) {
+            const int64_t wgs = (int64_t)a.dil * a.dil * fg.tiles_y * fg.tiles_x * vt_cdiv(a.coutT, FK_BN);   // per image
+            static const int fk_max_wgs = [] {   // VT_FULLK_MAX_WGS: largest per-image grid the heuristic gives it
+                const char* e = getenv("VT_FULLK_MAX_WGS");
+                return e && atoi(e) > 0 ? atoi(e) : 1024;
+            }();
+            if (hinted || fk_mode >= 2 || (a.coutT >= 128 && wgs <= fk_max_wgs)) {
+                t.kind = 4;
+                t.bm = FK_TH * FK_TW;
+                t.bn = FK_BN;
+                t.splitk = 1;
+                return t;
+            }
+        }
+    }
+    const bool can_patch = hp != 2 && hp != 4 && patch_eligible<T>(a, g);
     int units = 0;  // K units that can be split: K-steps (1-D) or channel chunks (patch)
-    if (hbm > 0) {
+    if (hbm > 0 && hp != 4) {
         t.kind = hp == 1 ? 1 : 0;
         t.bm = hbm;
         t.bn = hbn;
@@ -1810,6 +1837,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
     }
+    if (t.kind == 4) {
+        FullkArgs fg;
+        if (!fullk_eligible<T>(a, a.wstream, fg)) {
+            vt_set_error("vt_conv2d: whole-K kernel requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+        return launch_fullk<T>(a, fg, stream);
+    }
     if (t.kind == 3) {
         GldsArgs g;
         if (!c32_eligible<T>(a, g)) {
@@ -1917,6 +1952,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     }
     a.alpha_dev = d->alpha_dev;
     a.post_relu = d->post_relu ? 1 : 0;
+    a.wstream = d->weight_stream;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;
     a.resid = d->resid;
@@ -2003,6 +2039,34 @@ extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, big);
     if (t.splitk <= 1) return 0;
     return VT_TICKET_BYTES + (int64_t)t.splitk * a.M * slab_ld(a.coutT) * 4;
+}
+
+extern "C" int64_t vt_conv_weight_stream_bytes(int cout, int taps, int cin, int dtype) {
+    if (cout <= 0 || taps <= 0 || cin <= 0 || (dtype != VT_F32 && dtype != VT_BF16)) return -1;
+    const int esz = dtype == VT_F32 ? 4 : 2;
+    const int bk = 128 / esz;
+    if (cin % bk != 0) return -1;
+    return (int64_t)vt_cdiv(cout, FK_BN) * (cin / bk) * taps * 4 * 1024;
+}
+
+extern "C" int vt_conv_weight_stream(void* out, const void* packed, int cout, int taps, int cin, int dtype,
+                                     vt_stream stream) {
+    VT_REQUIRE(out && packed, "vt_conv_weight_stream: null tensor");
+    const int64_t bytes = vt_conv_weight_stream_bytes(cout, taps, cin, dtype);
+    VT_REQUIRE(bytes > 0, "vt_conv_weight_stream: unsupported shape/dtype (cout %d, taps %d, cin %d, dtype %d)", cout, taps,
+               cin, dtype);
+    VT_REQUIRE(((uintptr_t)out % 16 == 0) && ((uintptr_t)packed % 16 == 0), "vt_conv_weight_stream: 16-byte alignment");
+    const int64_t total16 = bytes / 16;
+    int64_t blocks = (total16 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == VT_BF16) {
+        auto k = weight_stream_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (bf16_t*)out, (const bf16_t*)packed, cout, taps, cin, total16);
+    } else {
+        auto k = weight_stream_kernel<float>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (float*)out, (const float*)packed, cout, taps, cin, total16);
+    }
+    return vt_check_launch("vt_conv_weight_stream");
 }
 
 // ---------------------------------------------------------------------------------

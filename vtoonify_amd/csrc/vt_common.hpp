@@ -272,6 +272,47 @@ __device__ __forceinline__ void vt_lds_barrier() {
 __device__ __forceinline__ int vt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// ---------------------------------------------------------------------------------
+// Register-destination global loads the COMPILER DOES NOT SEE (inline asm), for operands that are
+// streamed many sub-steps ahead of their use: hipcc sinks an ordinary load down to its first use and
+// waits vmcnt(0) there (observed on the whole-K conv kernel: the 6-deep weight ring collapsed into
+// load -> wait -> MFMA).  Contract (cdna_hip_programming.md 5.7, form iii): the destination registers
+// count as written at the statement, so nothing may read them before vt_vmcnt_fence<N>() has run with
+// N = the number of vector-memory operations this wave issued AFTER the load; the fence also stops the
+// scheduler from hoisting register-only consumers (MFMAs) above the wait.
+//   base: wave-uniform pointer (SGPR pair), voff: per-lane byte offset; loads 16 B at +0 and at +1024.
+// ---------------------------------------------------------------------------------
+#ifdef VT_EMU
+static inline void vt_gload16_pair_hidden(u128& a, u128& b, const void* base, uint32_t voff) {
+    a = ld128((const unsigned char*)base + voff);
+    b = ld128((const unsigned char*)base + voff + 1024);
+}
+template <int N>
+static inline void vt_vmcnt_fence() {
+    // lanes are coroutines here: the rendezvous stands for "the whole wave's loads have landed" (a wave's own
+    // LDS-DMA data is read back by OTHER lanes of the wave without a workgroup barrier in between)
+    const int dummy = 0;
+    (void)emu::exchange(&dummy, (int)sizeof(dummy));
+}
+#else
+typedef uint32_t vt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vt_gload16_pair_hidden(u128& a, u128& b, const void* base, uint32_t voff) {
+    vt_u32x4 x, y;
+    // s_nop 4: the base may have just come from a v_readfirstlane (VALU write of an SGPR -> VMEM read of it)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                 : "=&v"(x), "=&v"(y)
+                 : "v"(voff), "s"(base));
+    a = __builtin_bit_cast(u128, x);
+    b = __builtin_bit_cast(u128, y);
+}
+template <int N>
+__device__ __forceinline__ void vt_vmcnt_fence() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
 // wavefront (64 lanes) all-reduce sum via xor shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -76,7 +76,9 @@ class VToonifyEngine:
         self.dt = K.dt_code(dtype)
         self.esz = 2 if dtype == torch.bfloat16 else 4
         any_t = next(iter(state_dict.values()))
-        self.device = device or any_t.device
+        self.device = torch.device(device) if device is not None else any_t.device
+        if self.device.type == "cuda" and self.device.index is None:   # "cuda" == the current device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.lib()
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
@@ -137,6 +139,16 @@ class VToonifyEngine:
             self.w[f"to_rgbs.{i}.bias"] = sd[f"{self.g}to_rgbs.{i}.bias"].reshape(3).contiguous()
         self.fir_up = sd[f"{self.g}convs.6.conv.blur.kernel"].contiguous()
         self.fir_rgb = sd[f"{self.g}to_rgbs.3.upsample.kernel"].contiguous()
+        # fragment-stream images of the static 3x3 weights (vt_conv_weight_stream): lets vt_conv2d run the
+        # few-pixel / wide-channel layers (the H/8 x W/8 trunk) on the whole-K kernel -- no split-K slabs
+        self._wstream: Dict[int, torch.Tensor] = {}
+        if os.environ.get("VT_FULLK_KERNEL", "1") != "0":
+            unit = 8 * (64 if T == torch.bfloat16 else 32)
+            for key, wt in self.w.items():
+                if wt.ndim == 3 and wt.shape[1] == 9 and wt.shape[2] % unit == 0 and wt.shape[0] % 8 == 0:
+                    st = K.conv_weight_stream(wt)
+                    if st is not None:
+                        self._wstream[wt.data_ptr()] = st
 
     # ------------------------------------------------------------------ plan helpers
     def _buf(self, plan: _Plan, name: str, shape, dtype=None) -> torch.Tensor:
@@ -162,6 +174,9 @@ class VToonifyEngine:
         (`ref_macs` overrides that for the fused conv_transpose2d+blur form, whose polyphase
         filters do 4x the transposed conv's MACs), bytes = every operand read once + the
         output written once."""
+        wt = kw.get("weight")
+        if isinstance(wt, torch.Tensor) and wt.data_ptr() in self._wstream:
+            kw["weight_stream"] = self._wstream[wt.data_ptr()]
         d = self._apply_hint(K.make_conv_desc(dtype=self.dt, **kw))
         plan.keep.append(d)
         cin = d.c0 + d.c1
@@ -550,7 +565,7 @@ class VToonifyEngine:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
             kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
-                     3: "conv3x3_c32_kernel"}[kind]
+                     3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1:
@@ -576,8 +591,29 @@ class VToonifyEngine:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return C.c_void_p(0)
 
-    def _rows_equal(self, style: torch.Tensor) -> bool:
-        return bool((style == style[:1]).all().item())
+    def _rows_equal(self, style: torch.Tensor, owner: Optional[torch.Tensor] = None) -> bool:
+        """Do all frames of the batch share one style?  Decided without touching the device when the tensor says
+        so itself (one row, or an expand() view: stride 0); otherwise ONE comparison + host sync per distinct
+        caller tensor `owner` (same object and version counter; a reference is kept so its address cannot be
+        recycled), e.g. the `s_w.repeat(B,1,1)` of style_transfer.py:176 reused for every batch of a video."""
+        if style.shape[0] == 1 or style.stride(0) == 0:
+            return True
+        if owner is not None and getattr(self, "_rows_ref", None) is owner and \
+                self._rows_ver == getattr(owner, "_version", 0):
+            return self._rows_val
+        val = bool((style == style[:1]).all().item())
+        self._rows_ref, self._rows_ver, self._rows_val = owner, getattr(owner, "_version", 0), val
+        return val
+
+    def _auto_lane(self) -> int:
+        """Lane for the calling HIP stream: frames issued on different streams must not share plan buffers."""
+        if self.device.type != "cuda":
+            return 0
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        lanes = self.__dict__.setdefault("_stream_lanes", {})
+        if sid not in lanes:
+            lanes[sid] = len(lanes)
+        return lanes[sid]
 
     def map_style(self, z: torch.Tensor) -> torch.Tensor:
         """VToonify.zplus2wplus (model/vtoonify.py:285-286): 8-layer mapping network."""
@@ -593,18 +629,25 @@ class VToonifyEngine:
     @torch.no_grad()
     def forward(self, x: torch.Tensor, style: torch.Tensor, d_s=None, return_mask: bool = False,
                 return_feat: bool = False, shared_style: Optional[bool] = None,
-                use_graph: bool = False, lane: int = 0) -> torch.Tensor:
+                use_graph: Optional[bool] = None, lane: Optional[int] = None) -> torch.Tensor:
         """`lane` selects an independent set of plan buffers (activations, split-K workspace, graph):
         frames issued on different HIP streams must use different lanes, so that two frames of a
-        video can be in flight on one GPU (frames are independent)."""
-        if x.device != self.device and not (x.device.type == self.device.type == "cpu"):
+        video can be in flight on one GPU (frames are independent).  None = one
+        lane per calling stream.  `use_graph` None = hipGraph replay on a GPU (captured on the first
+        call of a shape), eager launches under host emulation."""
+        if x.device.type != self.device.type or (x.device.type == "cuda" and x.device.index != self.device.index):
             raise _lib.VtError(f"input on {x.device}, engine on {self.device}")
+        if use_graph is None:
+            use_graph = self.device.type == "cuda"
+        if lane is None:
+            lane = self._auto_lane()
         B, cin, H, W = x.shape
         if H % 8 or W % 8:
             raise _lib.VtError("H and W must be multiples of 8 (util.py:184-187 crops to //8*8)")
         if self.dual and d_s is None:
             raise TypeError("VToonify-D needs a style degree d_s (model/vtoonify.py:124)")
         d_s = 0.0 if d_s is None else float(d_s)
+        style_arg = style
         style = style.detach().to(self.device, torch.float32)
         if style.ndim == 2:  # W space (vtoonify.py:212-215)
             style = style[:, None, :].expand(-1, N_LATENT, -1)
@@ -614,7 +657,7 @@ class VToonifyEngine:
         if style.shape[0] not in (1, B):
             raise _lib.VtError("style batch must be 1 or match the frame batch")
         if shared_style is None:
-            shared_style = style.shape[0] == 1 or B == 1 or self._rows_equal(style)
+            shared_style = style.shape[0] == 1 or B == 1 or self._rows_equal(style, style_arg)
         has_res = self.dual and d_s != 0.0  # AdaResBlock early-out (dualstylegan.py:40-41)
         key = (B, H, W, bool(shared_style), has_res) + ((lane,) if lane else ())
         plan = self._plans.get(key)
@@ -626,16 +669,24 @@ class VToonifyEngine:
         # ---- per-call inputs into the plan's static buffers ---------------------------
         srows = style[:1] if shared_style else style
         # the style products (modulated weights, AdaIN gamma/beta) live in the plan's own buffers, so the
-        # cache key is per plan: lanes that alternate frame by frame each keep their cache warm
-        skey = (srows.data_ptr(), getattr(srows, "_version", 0), d_s, wspace)
-        need_style = not (self.cache_styles and skey == getattr(plan, "style_key", None))
+        # cache key is per plan: lanes that alternate frame by frame each keep their cache warm.  A hit needs
+        # the caller's OWN tensor (same object, same version counter, no dtype/device conversion on the way
+        # in -- a converted temporary can reuse a freed address with version 0); the plan keeps a reference,
+        # so the address cannot be recycled while it is the key.  Edits through `.data` bypass the version
+        # counter: pass a new tensor (or cache_styles=False) for those.
+        own = style_arg.device == self.device and style_arg.dtype == torch.float32
+        hit = (self.cache_styles and own and getattr(plan, "style_ref", None) is style_arg and
+               getattr(plan, "style_key", None) == (getattr(style_arg, "_version", 0), d_s, wspace, bool(shared_style)))
+        need_style = not hit
         if "x_in" not in plan.bufs:
             self._buf(plan, "x_in", (B, cin, H, W), torch.float32)
         plan.bufs["x_in"].copy_(x.detach())
         if need_style:
             plan.bufs["style_in"].copy_(srows)
             plan.bufs["d_s"].fill_(d_s)
-            plan.style_key = skey if self.cache_styles else None
+            cacheable = self.cache_styles and own
+            plan.style_ref = style_arg if cacheable else None
+            plan.style_key = (getattr(style_arg, "_version", 0), d_s, wspace, bool(shared_style)) if cacheable else None
         if use_graph and self.device.type == "cuda" and not return_feat:
             self._replay(plan, need_style)
         else:

@@ -94,7 +94,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
                    in_shift=None, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, alpha=1.0, beta=0.0,
                    alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None,
                    tile_hint=0, splitk_ws=None, slope_vec=None, rgb_weight=None, rgb_bias=None, rgb_resid=None,
-                   rgb_out=None, stats_part=None, post_relu=0) -> ConvDesc:
+                   rgb_out=None, stats_part=None, post_relu=0, weight_stream=None) -> ConvDesc:
     """Fill a vt_conv_desc.  Pointers may be tensors or raw ints (sub-views: data_ptr()+offset)."""
     d = ConvDesc()
     d.src0, d.src1 = _ptr(src0), _ptr(src1)
@@ -118,6 +118,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
     d.rgb_weight, d.rgb_bias, d.rgb_resid, d.rgb_out = _ptr(rgb_weight), _ptr(rgb_bias), _ptr(rgb_resid), _ptr(rgb_out)
     d.stats_part = _ptr(stats_part)
     d.post_relu = int(post_relu)
+    d.weight_stream = _ptr(weight_stream)
     if splitk_ws is not None:  # fp32 workspace tensor enabling split-K (see vt_conv2d_ws_bytes)
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     return d
@@ -144,6 +145,21 @@ def pack_conv_weight(w: torch.Tensor, cin_dst=None, chan_map=None, scale=1.0, sr
     _lib.check(_lib.lib().vt_pack_conv_weight(_p(out), _p(w), cout, cin_src, kh, kw, cin_dst, _p(chan_map),
                                              float(scale), int(src_transposed), dt_code(out_dtype),
                                              _stream(w)), "vt_pack_conv_weight")
+    return out
+
+
+def conv_weight_stream(packed: torch.Tensor):
+    """packed [cout][taps][cin] (pack_conv_weight / modulate_weight layout) -> its fragment-stream image for
+    the whole-K conv kernel (vt_conv_desc.weight_stream), or None when the shape has none."""
+    _dev_ok(packed)
+    cout, taps, cin = packed.shape
+    dt = dt_code(packed.dtype)
+    nbytes = int(_lib.lib().vt_conv_weight_stream_bytes(cout, taps, cin, dt))
+    if nbytes <= 0:
+        return None
+    out = torch.empty((nbytes // packed.element_size(),), dtype=packed.dtype, device=packed.device)
+    _lib.check(_lib.lib().vt_conv_weight_stream(_p(out), _p(packed), cout, taps, cin, dt, _stream(packed)),
+               "vt_conv_weight_stream")
     return out
 
 

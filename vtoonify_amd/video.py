@@ -88,8 +88,9 @@ class _Slot:
                           if pc and host_parsing else None)
         self.d_rgb = torch.empty((B, 3, H, W), dtype=torch.float32, device=device) if pc and not host_parsing else None
         self.h_out = torch.empty((B, 4 * H, 4 * W, 3), dtype=torch.uint8, pin_memory=cuda)
-        self.d_frames = torch.empty((B, H, W, 3), dtype=torch.uint8, device=device)
-        self.d_parsing = torch.empty((B, pc, H, W), dtype=torch.float32, device=device) if pc else None
+        # zero-filled: a ragged final batch runs the full-B plan over whatever the unused rows hold
+        self.d_frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=device)
+        self.d_parsing = torch.zeros((B, pc, H, W), dtype=torch.float32, device=device) if pc else None
         self.d_x = torch.empty((B, 3 + pc, H, W), dtype=torch.float32, device=device)
         self.d_out = torch.empty((B, 4 * H, 4 * W, 3), dtype=torch.uint8, device=device)
         self.ev_up = torch.cuda.Event() if cuda else None
@@ -165,6 +166,9 @@ class VideoToonifier:
             slot.h_out[:n].copy_(slot.d_out[:n])
 
     def _compute(self, slot: _Slot, n: int, pc: int):
+        # a ragged final batch (n < B) still runs the B-frame plan: one set of plan buffers and one hipGraph
+        # per lane, no capture in the middle of the pipeline; rows n..B-1 are stale and never retired
+        n = self.B
         if slot.d_rgb is not None:
             # no parsing maps from the source: x_p = nearest_x0.5(BiSeNet(2 * bilinear_x2(x))[0]) on the
             # GPU (style_transfer.py:170-172); the /16 is vt_frame_pack's parsing_scale
