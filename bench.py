@@ -140,6 +140,66 @@ def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
                       f"22x{height}x{width} workload"}
 
 
+def pin_to_gpu_numa_node(local_rank: int, ws: int):
+    """One process per GPU: keep this rank's host threads on the NUMA node its GPU hangs off and cap the
+    intra-op pool (8 ranks x a 256-thread default pool oversubscribe the host).  Best effort; returns what
+    was done for the JSON line."""
+    info = {"numa_node": None, "host_threads": None}
+    if ws == 1:   # a single rank owns the host (and the cpu_baseline leg wants all of its cores)
+        return info
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                cpus = set()
+                for part in f.read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                info["numa_node"] = node
+    except Exception:
+        pass
+    try:
+        n = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, ws if info["numa_node"] is None else 1)))
+        torch.set_num_threads(n)
+        info["host_threads"] = n
+    except Exception:
+        pass
+    return info
+
+
+def timed_blocks(step, steps, dev, min_seconds=1.0, max_blocks=64):
+    """Time blocks of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides, MAX over
+    ranks per block; blocks are repeated until >= min_seconds of timed work (same count on every rank: it is
+    derived from the reduced time of the first block).  Returns (median block seconds, [block seconds])."""
+    def one():
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+    times = [one()]
+    n = int(min(max_blocks, max(1, -(-min_seconds // max(times[0], 1e-6)))))
+    for _ in range(n - 1):
+        times.append(one())
+    srt = sorted(times)
+    return srt[len(srt) // 2], times
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +218,10 @@ def main():
                     help="JSON table {conv geometry: tile_hint} from tools/plan_sweep.py (default: built-in heuristics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the PCIe-inclusive video-driver measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys (batch4, module_call, config3); `value` is unaffected")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the --steps block until this much timed work has run; value = median block")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
     ap.add_argument("--op-iters", type=int, default=5, help="instrumented frames for per-kernel timing")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel table (stderr)")
@@ -179,6 +243,7 @@ def main():
     assert not _lib.is_emulation()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host = pin_to_gpu_numa_node(local_rank, ws)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     B, H, W = args.batch, args.height, args.width
 
@@ -221,32 +286,73 @@ def main():
     checksum = {"mean_abs": float(yf.abs().mean()), "max_abs": float(yf.abs().max()),
                 "samples": [float(v) for v in yf.flatten()[:: max(1, yf.numel() // 8)][:8]]}
 
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, blocks = timed_blocks(step, args.steps, dev, args.min_seconds)
+
+    def lanes_rate(bb, hh, ww, nsteps):
+        """frames/s of another (batch, size) on the same engine, `lanes` steps in flight, all ranks."""
+        pl = [synth.synth_frames(bb, hh, ww, seed=5000 + 1000 * rank + i).to(dev) for i in range(2)]
+        def st(i):
+            ln = i % lanes
+            with torch.cuda.stream(streams[ln]):
+                return eng.forward(pl[i % 2], style, d_s, shared_style=True, use_graph=use_graph, lane=ln)
+        for i in range(lanes + 2):
+            st(i)
+            if i < lanes:
+                torch.cuda.synchronize()
+        el, bl = timed_blocks(st, nsteps, dev, min(args.min_seconds, 0.5))
+        return {"value": ws * nsteps * bb / el, "unit": "frames/s", "frames_per_step_per_gpu": bb,
+                "ms_per_step": 1e3 * el / nsteps, "steps": nsteps, "blocks": len(bl), "frames_in_flight_per_gpu": lanes,
+                "workload": f"22x{hh}x{ww} -> 3x{4 * hh}x{4 * ww}"}
+
+    extras = {}
+    if not args.no_extras:
+        # the reference's default --batch_size 4 (style_transfer.py:35) on the headline frame size, and BASELINE
+        # config 3's per-rank step (4 frames of 22x144x256; 960 frames over the job = 240 / world_size steps)
+        extras["batch4"] = lanes_rate(4, H, W, 24)
+        extras["config3"] = lanes_rate(4, 144, 256, max(8, 240 // ws))
 
     # the same workload with ONE frame in flight (latency view; not `value`)
     single = None
+    module_call = None
     if rank == 0 and lanes > 1:
-        n1 = min(args.steps, 20)
+        n1 = min(args.steps, 50)
+        def s1(i):
+            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n1):
-            eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            for i in range(n1):
+                s1(i)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        t1 = sorted(ts)[len(ts) // 2]
+        single = {"value": n1 * B / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1e3 * t1 / n1,
+                  "frames_in_flight": 1, "blocks": len(ts)}
+    if rank == 0 and not args.no_extras:
+        # through the drop-in module: VToonify(...).load_state_dict(...); model(x, s_w.repeat(B,1,1), d_s=...)
+        # exactly as style_transfer.py:62-64,176 calls it (hipGraph replay by default, one frame in flight)
+        from vtoonify_amd.vtoonify import VToonify
+        m = VToonify(backbone=args.backbone, compute_dtype=dtype)
+        m.load_state_dict({k: v for k, v in sd_dev.items()})
+        m = m.to(dev)
+        sw = style.repeat(B, 1, 1)
+        for i in range(5):
+            ym = m(pool[i % len(pool)], sw, d_s=d_s)
         torch.cuda.synchronize()
-        single = {"value": n1 * B / (time.perf_counter() - t1), "unit": "frames/s", "steps": n1,
-                  "ms_per_step": 1e3 * (time.perf_counter() - t1) / n1, "frames_in_flight": 1}
+        assert torch.equal(ym, eng.forward(pool[4 % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0))
+        n1 = min(args.steps, 50)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            for i in range(n1):
+                m(pool[i % len(pool)], sw, d_s=d_s)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        t1 = sorted(ts)[len(ts) // 2]
+        module_call = {"value": n1 * B / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1e3 * t1 / n1,
+                       "what": "VToonify.__call__(x, s_w.repeat(B,1,1), d_s=...) of the drop-in module, one frame in flight"}
+        del m
 
     result = None
     if rank == 0:
@@ -285,6 +391,10 @@ def main():
             roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["traffic"] = pmc_traffic(dom["kernel"])
+        # durations are RAW event-to-event times (previous op's end -> this op's end, dispatch gap included);
+        # an empty event pair costs `event_gap_us` on this box -- rocprofv3's begin->end durations are shorter
+        roofline["timing"] = "hipEvent pairs around every launch, raw"
+        roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
         roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
                          "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
                          "kernel_sum_ms_per_frame": frame_ms})
@@ -306,6 +416,8 @@ def main():
             and args.backbone == "dualstylegan" else f"frames/sec at {4 * W}x{4 * H} VToonify inference",
             "value": fps, "unit": "frames/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "timed_blocks": len(blocks), "timed_seconds": sum(blocks), "block_ms_per_step_min_max":
+            [1e3 * min(blocks) / args.steps, 1e3 * max(blocks) / args.steps],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"VToonify-{'D' if args.backbone == 'dualstylegan' else 'T'} "
                                    f"22x{H}x{W} -> 3x{4 * H}x{4 * W}, batch {B} per GPU, d_s={d_s}, "
@@ -314,9 +426,12 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "frames_in_flight_per_gpu": lanes, "tile_hints": args.tile_hints or None,
                        "splitk_workgroup_target": int(os.environ.get("VT_SPLITK_WGS", "256")),
-                       "weight_broadcast_s": t_bcast},
+                       "weight_broadcast_s": t_bcast, "host": host,
+                       "per_rank_frames_per_s": fps / ws},
             "roofline": roofline,
             "single_stream": single,
+            "module_call": module_call,
+            **extras,
             "output_checksum": checksum,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                         for r in rows[:8]],

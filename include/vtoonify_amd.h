@@ -158,6 +158,22 @@ typedef struct vt_conv_desc {
                               order).  Enables the whole-K kernel for 3x3 stride-1 pad == dil convs whose channel
                               count is a multiple of 512 (bf16) / 256 (fp32): few-pixel, wide-channel layers run
                               without split-K slabs and without a reduce pass (KIND 4 of vt_conv2d_tile) */
+    /* AdaIN / InstanceNorm folded into whole-K convolutions (model/dualstylegan.py:6-21,38-45: every conv of an
+     * AdaResBlock is preceded by AdaIN of the previous conv's output).  Both ends must run the whole-K kernel
+     * (vt_conv2d_tile KIND 4), VT_ERR_UNSUPPORTED otherwise:
+     *   tile_stats     out: per (image, 8x8-pixel tile of THIS conv, channel) {mean, M2} fp32 records of the
+     *                  tensor this conv writes (the rounded values as stored), vt_conv_tile_stats_bytes() bytes;
+     *   in_tile_stats  in: such records of the tensor read through src0, written by a conv of dilation
+     *                  in_stats_dil; the kernel merges them in tile order (fp64) into mean / biased variance per
+     *                  (image, channel), eps 1e-5, and convolves AdaIN(x) = x*gamma*rstd + (beta - gamma*rstd*mean)
+     *                  (rounded to `dtype` like a stored tensor; zero padding stays zero) instead of x;
+     *   in_gb          [n or 1][2*c0] fp32, gamma first (the style Linear of AdaptiveInstanceNorm), row stride
+     *                  in_ld_gb (0: one style for the batch); NULL = plain InstanceNorm (gamma 1, beta 0). */
+    void* tile_stats;
+    const void* in_tile_stats;
+    int32_t in_stats_dil;
+    const float* in_gb;
+    int32_t in_ld_gb;
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
@@ -183,6 +199,8 @@ int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_src, int kh
  * feeds to the MFMA as its weight operand, in lane order; rows beyond cout are zero.
  * vt_conv_weight_stream_bytes gives the size of `out` (> 0) or -1 for unsupported shapes. */
 int64_t vt_conv_weight_stream_bytes(int cout, int taps, int cin, int dtype);
+/* Bytes of a vt_conv_desc.tile_stats buffer for an (n, h, w, c) output written by a conv of dilation `dil`. */
+int64_t vt_conv_tile_stats_bytes(int n, int h, int w, int dil, int c);
 int vt_conv_weight_stream(void* out, const void* packed, int cout, int taps, int cin, int dtype,
                           vt_stream stream);
 

@@ -4,10 +4,14 @@ path) and (2) the CPU oracle at full benchmark size on the GPU box.
 
 Stated tolerances (un-clamped output image, relative to the reference's max-abs):
   fp32 mode : max-abs error <= 1e-4 x max|ref|          (measured ~5e-6)
-  bf16 mode : max-abs error <= 6e-2 x max|ref|, PSNR >= 35 dB over the reference's range
-              (bf16 has no counterpart in the reference; fp32 accumulate everywhere,
-               fp32 statistics / demodulation / RGB skip path)
+  bf16 mode : max-abs error <= 3e-2 x max|ref|, PSNR >= 40 dB over the reference's range
+              (measured 1.0-1.6e-2 / 51-56 dB.  bf16 has no counterpart in the
+               reference; fp32 accumulate everywhere, fp32 statistics / demodulation / RGB skip path)
+Every comparison appends (what, dtype, max-rel, PSNR) to gpurun_out/parity_metrics.jsonl when that
+directory exists (the GPU box), so the measured margins are on record, not only pass/fail.
 """
+import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -18,7 +22,8 @@ from vtoonify_amd.engine import VToonifyEngine
 from vtoonify_amd.vtoonify import VToonify
 
 FP32_TOL = 1e-4
-BF16_TOL, BF16_PSNR = 6e-2, 35.0
+BF16_TOL, BF16_PSNR = 3e-2, 40.0
+_METRICS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 BB = {"D": "dualstylegan", "T": "toonify"}
 _cache = {}
 
@@ -33,12 +38,18 @@ def engine(tag, dtype, dev):
 
 
 def check(y, ref, dtype, what=""):
+    dev_type = y.device.type
     y = y.float().cpu().numpy()
     e = rel_err(y, ref)
+    p = psnr(y, ref, float(ref.max() - ref.min()))
+    print(f"[parity] {what} {str(dtype).split('.')[-1]} on {dev_type}: max-rel {e:.3e}, PSNR {p:.1f} dB")
+    if dev_type == "cuda" and os.path.isdir(_METRICS):
+        with open(os.path.join(_METRICS, "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"what": what, "dtype": str(dtype).split(".")[-1], "max_rel": e,
+                                "psnr_db": None if np.isinf(p) else p, "shape": list(ref.shape)}) + "\n")
     if dtype == torch.float32:
         assert e < FP32_TOL, f"{what}: {e:.2e}"
     else:
-        p = psnr(y, ref, float(ref.max() - ref.min()))
         assert e < BF16_TOL and p > BF16_PSNR, f"{what}: rel {e:.2e}, psnr {p:.1f} dB"
 
 
@@ -94,6 +105,38 @@ def test_module_dropin_surface(dev):
         m(torch.zeros(1, 22, 30, 32, device=dev), s)
 
 
+def test_style_cache_is_keyed_on_the_callers_tensor(dev):
+    """with cache_styles=True a CPU / fp64 / fp16 style is converted into a fresh temporary on
+    every call; a key made of that temporary's (address, version) can alias a different style.  The cache
+    only ever hits on the caller's own device-fp32 tensor object (same version counter)."""
+    d, _ = load_golden("e2e_T.npz")
+    sd = synth.synth_state_dict(load_keys("T"), 0)
+    eng = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, "toonify", 256, torch.float32, dev, cache_styles=True)
+    x = torch.from_numpy(d["x"]).to(dev)
+    s = torch.from_numpy(d["style"])
+    want = {}
+    for i in range(4):   # distinct styles through a converting path (fp64 on the host): never a stale hit
+        si = (s + 0.05 * i).double()
+        y = eng.forward(x, si, 0.5)
+        want[i] = y.clone()
+        if i:
+            assert not torch.equal(want[i], want[i - 1]), i
+    ref = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, "toonify", 256, torch.float32, dev)
+    for i in range(4):
+        assert torch.equal(ref.forward(x, (s + 0.05 * i).double(), 0.5), want[i]), i
+    # the caller's own tensor: second call hits, an in-place edit (version bump) misses
+    own = s.to(dev).clone()
+    y0 = eng.forward(x, own, 0.5)
+    plan = eng.plan_for(1, x.shape[2], x.shape[3], True, False)
+    assert plan.style_ref is own
+    assert torch.equal(eng.forward(x, own, 0.5), y0)
+    own.add_(0.1)
+    y1 = eng.forward(x, own, 0.5)
+    assert not torch.equal(y1, y0) and torch.equal(y1, ref.forward(x, own, 0.5))
+    # an engine built with device "cuda" / a device string accepts inputs on the indexed device (ADVICE r1)
+    assert eng.device == x.device
+
+
 def test_style_cache_and_determinism(dev):
     d, _ = load_golden("e2e_D.npz")
     eng = engine("D", torch.bfloat16, dev)
@@ -122,10 +165,14 @@ def test_style_cache_and_determinism(dev):
 
 # ------------------------------------------------------------------ full-size, GPU only
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,hw", [("D", (256, 256)), ("T", (144, 256))])
+@pytest.mark.parametrize("tag,hw", [("D", (256, 256)), ("T", (144, 256)),
+                                    ("T", (256, 256)),        # config 4 (VToonify-T at 1024x1024)
+                                    ("D", (384, 384)),        # config 5: 1536x1536
+                                    ("D", (360, 400))])       # config 5: the demo's crop, 45x50-pixel trunk (tile edges)
 def test_full_size_fp32_vs_oracle(tag, hw):
-    """BASELINE config 1/2 (22x256x256 -> 3x1024x1024) and config 3's frame size, fp32 HIP
-    vs the CPU oracle on identical seeded weights / inputs."""
+    """Every BASELINE configuration's frame geometry (configs 1/2: D 256x256; 3: 144x256; 4: T 256x256;
+    5: D 384x384 and the non-power-of-two 360x400), fp32 AND bf16 HIP vs the CPU oracle on identical
+    seeded weights / inputs."""
     from oracle import vtoonify_oracle as O
     from vtoonify_amd import _lib
     _lib.use_library(_lib.DEFAULT_LIB)
@@ -145,6 +192,29 @@ def test_full_size_fp32_vs_oracle(tag, hw):
     check(y, ref, torch.float32, f"{tag} {hw}")
     yb = engine(tag, torch.bfloat16, dev).forward(x.to(dev), s.to(dev), 0.5)
     check(yb, ref, torch.bfloat16, f"{tag} {hw} bf16")
+
+
+@pytest.mark.gpu
+def test_config3_batch4_vs_oracle():
+    """BASELINE config 3's per-rank step: D, 4 frames of 22x144x256 per call (the reference's --batch_size 4,
+    style_transfer.py:35,176 `s_w.repeat(B,1,1)`), fp32 and bf16 vs the oracle, every frame of the batch."""
+    from oracle import vtoonify_oracle as O
+    from vtoonify_amd import _lib
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    sd = synth.synth_state_dict(load_keys("D"), 0)
+    x = synth.synth_frames(4, 144, 256, seed=31)
+    s = synth.synth_style(seed=17)
+    old = O.set_backend("torch")
+    try:
+        ref = np.concatenate([O.vtoonify_forward(synth.to_numpy_sd(sd), x[i:i + 1].numpy(), s.numpy(), 0.5,
+                                                 "dualstylegan") for i in range(4)], 0)
+    finally:
+        O.set_backend(old)
+    for dtype in (torch.float32, torch.bfloat16):
+        y = engine("D", dtype, dev).forward(x.to(dev), s.to(dev).repeat(4, 1, 1), 0.5)
+        assert tuple(y.shape) == (4, 3, 576, 1024)
+        check(y, ref, dtype, "D 4x(144,256)")
 
 
 @pytest.mark.gpu

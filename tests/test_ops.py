@@ -677,3 +677,66 @@ def test_conv_whole_k_kernel(dev, dtype):
             want = ref * 0.5 + 0.25 * r.float().cpu().permute(0, 3, 1, 2).numpy()
         assert rel_err(outs[0], want) < t, (N, c0, c1, H, W, Cout, dil)
         assert rel_err(outs[0], outs[1]) < t, "whole-K kernel vs the slab path"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_whole_k_adain_chain(dev, dtype):
+    """AdaResBlock on the whole-K kernel (model/dualstylegan.py:38-45): conv A writes its output AND per-tile
+    {mean, M2} records (vt_conv_desc.tile_stats); conv B merges them, applies AdaIN to its input patch in LDS
+    and convolves -- no statistics / normalisation launches in between.  Checked: the records against numpy on
+    the stored tensor, and conv B against conv(AdaIN(stored A)) from the oracle, for dilation 1/2/4 producers
+    and consumers, odd sizes, batch 2 with per-sample gamma/beta and with a shared row."""
+    g = np.random.default_rng(91)
+    t = 1e-4 if dtype == torch.float32 else 1.2e-2
+    unit = 256 if dtype == torch.float32 else 512
+    L = K.ACT_LRELU
+    for N, H, W, dA, dB, shared in [(1, 8, 8, 1, 1, True), (2, 9, 11, 1, 2, False), (1, 13, 6, 4, 1, True),
+                                    (2, 7, 10, 2, 4, True)]:
+        C = unit
+        x = g.standard_normal((N, C, H, W)).astype(np.float32)
+        wA = (g.standard_normal((C, C, 3, 3)) / math.sqrt(C * 9)).astype(np.float32)
+        wB = (g.standard_normal((40, C, 3, 3)) / math.sqrt(C * 9)).astype(np.float32)
+        bA = g.standard_normal(C).astype(np.float32)
+        gb = (1.0 + 0.3 * g.standard_normal((1 if shared else N, 2 * C))).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wpA, wpB = K.pack_conv_weight(T(wA, dev), out_dtype=dtype), K.pack_conv_weight(T(wB, dev), out_dtype=dtype)
+        ts = torch.zeros(K.conv_tile_stats_bytes(N, H, W, dA, C) // 4, dtype=torch.float32, device=dev)
+        yA = torch.zeros((N, H, W, C), dtype=dtype, device=dev)
+        K.conv2d(src0=xt, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpA, weight_stream=K.conv_weight_stream(wpA),
+                 cout=C, kh=3, kw=3, pad=dA, dil=dA, bias=T(bA, dev), act=L, gain=2 ** 0.5, out=yA, ld_out=C,
+                 dtype=K.dt_code(dtype), tile_stats=ts)
+        a = yA.float().cpu().permute(0, 3, 1, 2).numpy()                      # the tensor as stored
+        # ---- records: tile (phase_y, phase_x, tile_y, tile_x) of dilation dA, {mean, M2} per channel
+        ty, tx = -(-(-(-H // dA)) // 8), -(-(-(-W // dA)) // 8)
+        rec = ts.cpu().numpy().reshape(N, dA * dA * ty * tx, C, 2)
+        for n in range(N):
+            ti = 0
+            for fy in range(dA):
+                for fx in range(dA):
+                    for iy in range(ty):
+                        for ix in range(tx):
+                            blk = a[n, :, fy + iy * 8 * dA::dA, fx + ix * 8 * dA::dA][:, :8, :8].reshape(C, -1)
+                            if blk.shape[1]:
+                                m = blk.mean(1)
+                                assert np.abs(rec[n, ti, :, 0] - m).max() < 1e-5 * max(1.0, np.abs(m).max())
+                                m2 = ((blk - m[:, None]) ** 2).sum(1)
+                                assert np.abs(rec[n, ti, :, 1] - m2).max() < 1e-4 * max(1.0, m2.max())
+                            ti += 1
+        # ---- conv B on AdaIN(a): reference from the stored tensor (rounded to `dtype` like nrm_res was)
+        mean = a.mean((2, 3), keepdims=True)
+        var = a.var((2, 3), keepdims=True)
+        gam = np.broadcast_to(gb[:, :C, None, None], (N, C, 1, 1))
+        bet = np.broadcast_to(gb[:, C:, None, None], (N, C, 1, 1))
+        an = (a - mean) / np.sqrt(var + 1e-5) * gam + bet
+        an = torch.from_numpy(an.astype(np.float32)).to(dtype).float().numpy()
+        wq = wpB.float().cpu().numpy().reshape(40, 3, 3, C).transpose(0, 3, 1, 2)
+        ref = O.conv2d(an, wq, None, 1, dB, dB)
+        yB = torch.zeros((N, H, W, 40), dtype=dtype, device=dev)
+        K.conv2d(src0=yA, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpB, weight_stream=K.conv_weight_stream(wpB),
+                 cout=40, kh=3, kw=3, pad=dB, dil=dB, out=yB, ld_out=40, dtype=K.dt_code(dtype), tile_hint=4 * P,
+                 in_tile_stats=ts, in_stats_dil=dA, in_gb=T(gb, dev), in_ld_gb=0 if shared else 2 * C)
+        assert rel_err(yB.float().cpu().permute(0, 3, 1, 2).numpy(), ref) < t, (N, H, W, dA, dB)
+    # both ends must be whole-K plans
+    with pytest.raises(Exception, match="whole-K"):
+        K.conv2d(src0=xt, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpA, cout=C, kh=3, kw=3, pad=1,
+                 out=yA, ld_out=C, dtype=K.dt_code(dtype), tile_stats=ts)

@@ -52,6 +52,8 @@ class ConvDesc(C.Structure):
         ("stats_part", C.c_void_p),
         ("post_relu", C.c_int32),
         ("weight_stream", C.c_void_p),
+        ("tile_stats", C.c_void_p), ("in_tile_stats", C.c_void_p), ("in_stats_dil", C.c_int32),
+        ("in_gb", C.c_void_p), ("in_ld_gb", C.c_int32),
     ]
 
 
@@ -81,6 +83,7 @@ _SIGS = {
     "vt_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "vt_conv2d_ws_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "vt_conv_weight_stream_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vt_conv_tile_stats_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vt_conv_weight_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),

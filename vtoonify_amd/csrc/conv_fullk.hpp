@@ -46,6 +46,20 @@ constexpr int FK_ABYTES = FK_PA * 1024;                                        /
 constexpr int FK_DEPTH = 6;                                                    // weight sub-steps in flight (static_assert AHEAD ladder below)
 
 __device__ __forceinline__ int fk_swz(int px) { return ((px >> 1) & 3) << 1; }
+constexpr float FK_IN_EPS = 1e-5f;   // nn.InstanceNorm2d default (model/dualstylegan.py:10)
+
+// tile index within an image -> number of its pixels that lie inside the H x W image, for a tiling of dilation d
+__device__ __forceinline__ int fk_tile_count(int t, int d, int tiles_y, int tiles_x, int H, int W) {
+    const int per_phase = tiles_y * tiles_x;
+    const int ph = t / per_phase, rem = t - ph * per_phase;
+    const int fy = ph / d, fx = ph - fy * d;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    int ny = (H - fy + d - 1) / d - ty * FK_TH;   // rows of this phase at or below the tile's first row
+    int nx = (W - fx + d - 1) / d - tx * FK_TW;
+    ny = ny < 0 ? 0 : ny > FK_TH ? FK_TH : ny;
+    nx = nx < 0 ? 0 : nx > FK_TW ? FK_TW : nx;
+    return ny * nx;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(FK_NW * 64)
@@ -137,6 +151,59 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
 #pragma unroll
         for (int s = 0; s < FK_DEPTH; ++s) vt_gload16_pair_hidden(wr[s][0], wr[s][1], wcur + s * 2048, wlane);
         vt_vmcnt_fence<0>();   // patch + first weights landed (the compiler's own wait for the LDS-DMA drains both anyway)
+        if (p.in_tile_stats) {
+            // AdaIN prologue (model/dualstylegan.py:16-21 ahead of every AdaResBlock conv): merge the producer's
+            // per-tile {mean, M2} records of THIS wave's channels (lane = channel; tile order, fp64 -- the same
+            // in every workgroup, every batch size), park scale / shift in the 4 spare rows of the patch region,
+            // then rewrite the landed patch in place: x' = x * scale[c] + shift[c] for pixels inside the image
+            // (the zero padding of the conv applies to the NORMALISED tensor), rounded to T like a stored tensor.
+            const int cl = lane & (BK - 1);
+            const int kc = (r * FK_NW + wave) * BK;
+            const int d2 = p.in_stats_dil;
+            const int t2y = vt_cdiv_dev(vt_cdiv_dev(p.H, d2), FK_TH), t2x = vt_cdiv_dev(vt_cdiv_dev(p.W, d2), FK_TW);
+            const int nt = d2 * d2 * t2y * t2x;
+            const float* rec = p.in_tile_stats + ((size_t)img * nt * p.cin + kc + cl) * 2;
+            double sum = 0.0;
+            for (int t = 0; t < nt; ++t)
+                sum += (double)rec[(size_t)t * p.cin * 2] * (double)fk_tile_count(t, d2, t2y, t2x, p.H, p.W);
+            const double hw = (double)p.H * (double)p.W;
+            const double mean = sum / hw;
+            double m2 = 0.0;
+            for (int t = 0; t < nt; ++t) {
+                const double dm = (double)rec[(size_t)t * p.cin * 2] - mean;
+                m2 += (double)rec[(size_t)t * p.cin * 2 + 1] + (double)fk_tile_count(t, d2, t2y, t2x, p.H, p.W) * dm * dm;
+            }
+            double var = m2 / hw;   // biased, as F.instance_norm
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)FK_IN_EPS));
+            float gamma = 1.0f, beta = 0.0f;
+            if (p.in_gb) {
+                gamma = p.in_gb[(size_t)img * p.in_ld_gb + kc + cl];
+                beta = p.in_gb[(size_t)img * p.in_ld_gb + p.cin + kc + cl];
+            }
+            float* tab = reinterpret_cast<float*>(my + FK_PROWS * 128);   // rows 100..103: [scale BK | shift BK]
+            if (lane < BK) {
+                tab[cl] = gamma * rstd;
+                tab[BK + cl] = beta - gamma * rstd * (float)mean;
+            }
+            vt_wave_sync();
+#pragma unroll
+            for (int i = 0; i < FK_PA; ++i) {
+                const int row = i * 8 + (lane >> 3);
+                const int py = row / FK_PW, px = row - py * FK_PW;
+                const int iy = y0 + (py - 1) * d, ix = x0 + (px - 1) * d;
+                const bool in = row < FK_PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                if (in) {
+                    const int jj = (lane & 7) ^ fk_swz(px);   // logical 16-byte chunk in this physical slot
+                    float f[VEC];
+                    unpack16<T>(ld128(my + i * 1024 + lane * 16), f);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) f[k] = f[k] * tab[jj * VEC + k] + tab[BK + jj * VEC + k];
+                    st128(my + i * 1024 + lane * 16, pack16<T>(f));
+                }
+            }
+            vt_wave_sync();
+        }
         u128 fa[2][4];
         read_a(fa[0], 0);
 #pragma unroll
@@ -185,7 +252,7 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     }
     const int oy = y0 + (px >> 3) * d, ox = x0 + (px & 7) * d;
     const int n = n0 + 4 * c4;
-    if (oy >= p.H || ox >= p.W || n >= p.coutT) return;
+    const bool live = oy < p.H && ox < p.W && n < p.coutT;
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -193,7 +260,94 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         const float bv = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
         f[i] = conv_finish(p, f[i], bv, ga, (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope);
     }
-    store_out4(p, (img * p.H + oy) * p.W + ox, n, f);
+    const int m = (img * p.H + oy) * p.W + ox;
+    if (!p.tile_stats) {
+        if (live) store_out4(p, m, n, f);
+        return;
+    }
+    // ---- output + its InstanceNorm tile record (host guarantees NHWC, T-typed, 8-byte aligned vector stores) ----
+    // the statistics are those of the ROUNDED values as stored: a later pass over the tensor would see the same
+    if (live) {
+        if (p.resid) {
+            float g4[4];
+            if (sizeof(T) == 2) {
+                const u64v rv = *reinterpret_cast<const u64v*>((const bf16_t*)p.resid + (int64_t)m * p.ld_res + n);
+                g4[0] = vt_u2f(rv.x << 16); g4[1] = vt_u2f(rv.x & 0xffff0000u);
+                g4[2] = vt_u2f(rv.y << 16); g4[3] = vt_u2f(rv.y & 0xffff0000u);
+            } else {
+                unpack16<float>(ld128((const float*)p.resid + (int64_t)m * p.ld_res + n), g4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] += p.beta * g4[i];
+        }
+        post_act_n<4>(p, f);
+        if (sizeof(T) == 2) {
+            u64v v;
+            v.x = pack_bf16x2(f[0], f[1]);
+            v.y = pack_bf16x2(f[2], f[3]);
+            *reinterpret_cast<u64v*>((bf16_t*)p.out + (int64_t)m * p.ld_out + n) = v;
+            f[0] = vt_u2f(v.x << 16); f[1] = vt_u2f(v.x & 0xffff0000u);
+            f[2] = vt_u2f(v.y << 16); f[3] = vt_u2f(v.y & 0xffff0000u);
+        } else {
+            st128((float*)p.out + (int64_t)m * p.ld_out + n, pack16<float>(f));
+        }
+    } else {
+        f[0] = f[1] = f[2] = f[3] = 0.0f;
+    }
+    // two passes over the tile's <= 64 pixels per channel: lanes 8 apart hold the 8 pixels of one tile row (same
+    // c4), the 8 wavefronts hold the 8 rows; fixed shuffle tree + wave order 0..7 => deterministic
+    const int tcount = fk_tile_count(tile_m - img * per_img, d, g.tiles_y, g.tiles_x, p.H, p.W);
+    float* xs = reinterpret_cast<float*>(smem);   // 8 waves x 32 channels
+    __syncthreads();   // every wave is done reading the partial tiles
+    float s4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = f[i];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        s4[i] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[wave * 32 + lane * 4 + i] = s4[i];
+    }
+    __syncthreads();
+    float mean4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < FK_NW; ++w) v += xs[w * 32 + c4 * 4 + i];
+        mean4[i] = tcount > 0 ? v / (float)tcount : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float dv = live ? f[i] - mean4[i] : 0.0f;
+        float v = dv * dv;
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        s4[i] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[wave * 32 + lane * 4 + i] = s4[i];
+    }
+    __syncthreads();
+    if (tid < 8 && n < p.coutT) {   // thread c4 writes the records of channels 4*c4 .. 4*c4+3
+        float* rec = p.tile_stats + ((size_t)tile_m * p.coutT + n) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (n + i >= p.coutT) break;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < FK_NW; ++w) v += xs[w * 32 + c4 * 4 + i];
+            rec[2 * i] = mean4[i];
+            rec[2 * i + 1] = v;
+        }
+    }
 }
 
 // fragment-stream image of packed weights [cout][taps][cin] (vt_conv_weight_stream)

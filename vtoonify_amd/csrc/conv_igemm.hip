@@ -78,6 +78,11 @@ struct ConvArgs {
     StatRec* stats_part;  // InstanceNorm chunk records of the output (vt_conv_desc.stats_part) or NULL
     int post_relu;      // vt_conv_desc.post_relu: max(., 0) after the residual add
     const void* wstream;  // vt_conv_desc.weight_stream: fragment-stream image of the weights (whole-K kernel) or NULL
+    float* tile_stats;          // whole-K kernel: {mean, M2} per (image, tile, channel) of the output, or NULL
+    const float* in_tile_stats; // whole-K kernel: records of the input tensor -> AdaIN prologue, or NULL
+    int in_stats_dil;
+    const float* in_gb;
+    int in_ld_gb;
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -1837,6 +1842,18 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
     }
+    if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
+        vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);
+        return VT_ERR_UNSUPPORTED;
+    }
+    if (a.tile_stats && !(a.out_layout == VT_OUT_NHWC && a.vec_store && a.out_f32 == (sizeof(T) == 4) && a.coutT % 8 == 0)) {
+        vt_set_error("vt_conv2d: tile_stats needs an NHWC output in the compute dtype with 16-byte aligned pixels");
+        return VT_ERR_UNSUPPORTED;
+    }
+    if (a.in_tile_stats && a.c1 != 0) {
+        vt_set_error("vt_conv2d: in_tile_stats (AdaIN prologue) supports a single source");
+        return VT_ERR_UNSUPPORTED;
+    }
     if (t.kind == 4) {
         FullkArgs fg;
         if (!fullk_eligible<T>(a, a.wstream, fg)) {
@@ -1953,6 +1970,11 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.alpha_dev = d->alpha_dev;
     a.post_relu = d->post_relu ? 1 : 0;
     a.wstream = d->weight_stream;
+    a.tile_stats = (float*)d->tile_stats;
+    a.in_tile_stats = (const float*)d->in_tile_stats;
+    a.in_stats_dil = d->in_stats_dil > 0 ? d->in_stats_dil : 1;
+    a.in_gb = d->in_gb;
+    a.in_ld_gb = d->in_ld_gb;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;
     a.resid = d->resid;
@@ -2047,6 +2069,11 @@ extern "C" int64_t vt_conv_weight_stream_bytes(int cout, int taps, int cin, int 
     const int bk = 128 / esz;
     if (cin % bk != 0) return -1;
     return (int64_t)vt_cdiv(cout, FK_BN) * (cin / bk) * taps * 4 * 1024;
+}
+
+extern "C" int64_t vt_conv_tile_stats_bytes(int n, int h, int w, int dil, int c) {
+    if (n <= 0 || h <= 0 || w <= 0 || dil <= 0 || c <= 0) return -1;
+    return (int64_t)n * dil * dil * vt_cdiv(vt_cdiv(h, dil), FK_TH) * vt_cdiv(vt_cdiv(w, dil), FK_TW) * c * 8;
 }
 
 extern "C" int vt_conv_weight_stream(void* out, const void* packed, int cout, int taps, int cin, int dtype,

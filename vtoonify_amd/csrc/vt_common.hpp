@@ -321,6 +321,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int vt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+__device__ __forceinline__ int vt_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// Lanes of ONE wavefront exchange data through LDS (a wave-private region): the hardware runs the wave's LDS
+// operations in order, so this is only a compiler scheduling fence; the host emulation, where lanes are
+// coroutines, needs a real rendezvous.
+#ifdef VT_EMU
+static inline void vt_wave_sync() {
+    const int dummy = 0;
+    (void)emu::exchange(&dummy, (int)sizeof(dummy));
+}
+#else
+__device__ __forceinline__ void vt_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#endif
 
 // ---- InstanceNorm chunk records, shared by norm_glue.hip and the conv kernels that emit them ----
 struct StatRec {

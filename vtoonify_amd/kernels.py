@@ -94,7 +94,8 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
                    in_shift=None, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, alpha=1.0, beta=0.0,
                    alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None,
                    tile_hint=0, splitk_ws=None, slope_vec=None, rgb_weight=None, rgb_bias=None, rgb_resid=None,
-                   rgb_out=None, stats_part=None, post_relu=0, weight_stream=None) -> ConvDesc:
+                   rgb_out=None, stats_part=None, post_relu=0, weight_stream=None, tile_stats=None,
+                   in_tile_stats=None, in_stats_dil=1, in_gb=None, in_ld_gb=0) -> ConvDesc:
     """Fill a vt_conv_desc.  Pointers may be tensors or raw ints (sub-views: data_ptr()+offset)."""
     d = ConvDesc()
     d.src0, d.src1 = _ptr(src0), _ptr(src1)
@@ -119,6 +120,8 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
     d.stats_part = _ptr(stats_part)
     d.post_relu = int(post_relu)
     d.weight_stream = _ptr(weight_stream)
+    d.tile_stats, d.in_tile_stats, d.in_stats_dil = _ptr(tile_stats), _ptr(in_tile_stats), int(in_stats_dil)
+    d.in_gb, d.in_ld_gb = _ptr(in_gb), int(in_ld_gb)
     if splitk_ws is not None:  # fp32 workspace tensor enabling split-K (see vt_conv2d_ws_bytes)
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     return d
@@ -146,6 +149,10 @@ def pack_conv_weight(w: torch.Tensor, cin_dst=None, chan_map=None, scale=1.0, sr
                                              float(scale), int(src_transposed), dt_code(out_dtype),
                                              _stream(w)), "vt_pack_conv_weight")
     return out
+
+
+def conv_tile_stats_bytes(n, h, w, dil, c) -> int:
+    return int(_lib.lib().vt_conv_tile_stats_bytes(n, h, w, dil, c))
 
 
 def conv_weight_stream(packed: torch.Tensor):
