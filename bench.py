@@ -391,10 +391,11 @@ def main():
             roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["traffic"] = pmc_traffic(dom["kernel"])
-        # durations are RAW event-to-event times (previous op's end -> this op's end, dispatch gap included);
-        # an empty event pair costs `event_gap_us` on this box -- rocprofv3's begin->end durations are shorter
-        roofline["timing"] = "hipEvent pairs around every launch, raw"
+        # durations: hipEvent pairs around every launch minus the median cost of an EMPTY event pair on this box
+        # (`event_gap_us`, ~5 us: the event packets' own dispatch); raw sum kept as `kernel_sum_ms_raw`
+        roofline["timing"] = "hipEvent pair per launch minus the empty-pair gap"
         roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
+        roofline["kernel_sum_ms_raw"] = sum(getattr(eng, "last_raw_ms", []))
         roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
                          "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
                          "kernel_sum_ms_per_frame": frame_ms})

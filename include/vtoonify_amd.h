@@ -162,7 +162,8 @@ typedef struct vt_conv_desc {
      * AdaResBlock is preceded by AdaIN of the previous conv's output).  Both ends must run the whole-K kernel
      * (vt_conv2d_tile KIND 4), VT_ERR_UNSUPPORTED otherwise:
      *   tile_stats     out: per (image, 8x8-pixel tile of THIS conv, channel) {mean, M2} fp32 records of the
-     *                  tensor this conv writes (the rounded values as stored), vt_conv_tile_stats_bytes() bytes;
+     *                  tensor this conv writes (the rounded values as stored), followed by the pixel count of
+     *                  every tile; vt_conv_tile_stats_bytes() bytes in all;
      *   in_tile_stats  in: such records of the tensor read through src0, written by a conv of dilation
      *                  in_stats_dil; the kernel merges them in tile order (fp64) into mean / biased variance per
      *                  (image, channel), eps 1e-5, and convolves AdaIN(x) = x*gamma*rstd + (beta - gamma*rstd*mean)

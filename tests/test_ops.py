@@ -708,7 +708,9 @@ def test_conv_whole_k_adain_chain(dev, dtype):
         a = yA.float().cpu().permute(0, 3, 1, 2).numpy()                      # the tensor as stored
         # ---- records: tile (phase_y, phase_x, tile_y, tile_x) of dilation dA, {mean, M2} per channel
         ty, tx = -(-(-(-H // dA)) // 8), -(-(-(-W // dA)) // 8)
-        rec = ts.cpu().numpy().reshape(N, dA * dA * ty * tx, C, 2)
+        nt = dA * dA * ty * tx
+        rec = ts.cpu().numpy()[:N * nt * C * 2].reshape(N, nt, C, 2)
+        cnt = ts.cpu().numpy()[N * nt * C * 2:].reshape(N, nt)
         for n in range(N):
             ti = 0
             for fy in range(dA):
@@ -716,6 +718,7 @@ def test_conv_whole_k_adain_chain(dev, dtype):
                     for iy in range(ty):
                         for ix in range(tx):
                             blk = a[n, :, fy + iy * 8 * dA::dA, fx + ix * 8 * dA::dA][:, :8, :8].reshape(C, -1)
+                            assert cnt[n, ti] == blk.shape[1]
                             if blk.shape[1]:
                                 m = blk.mean(1)
                                 assert np.abs(rec[n, ti, :, 0] - m).max() < 1e-5 * max(1.0, np.abs(m).max())

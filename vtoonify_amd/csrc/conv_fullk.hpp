@@ -150,30 +150,42 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         u128 wr[FK_DEPTH][2];
 #pragma unroll
         for (int s = 0; s < FK_DEPTH; ++s) vt_gload16_pair_hidden(wr[s][0], wr[s][1], wcur + s * 2048, wlane);
-        vt_vmcnt_fence<0>();   // patch + first weights landed (the compiler's own wait for the LDS-DMA drains both anyway)
+        // AdaIN prologue, part 1 (model/dualstylegan.py:16-21 ahead of every AdaResBlock conv): while the patch
+        // and the first weights are in flight, merge the producer's per-tile {mean, M2} records of THIS wave's
+        // channels (lane = channel) into scale / shift.  One pass, fp64, tile order (the same in every workgroup
+        // and for every batch size), shifted by the first tile's mean:
+        //   S1 = sum n_t (m_t - x0),  S2 = sum [M2_t + n_t (m_t - x0)^2];  mean = x0 + S1/N,  M2 = S2 - S1^2/N
+        // tile pixel counts n_t come from the producer (no index arithmetic here), loads are issued 16 at a time.
+        float ad_scale = 1.0f, ad_shift = 0.0f;
+        const int cl = lane & (BK - 1);
         if (p.in_tile_stats) {
-            // AdaIN prologue (model/dualstylegan.py:16-21 ahead of every AdaResBlock conv): merge the producer's
-            // per-tile {mean, M2} records of THIS wave's channels (lane = channel; tile order, fp64 -- the same
-            // in every workgroup, every batch size), park scale / shift in the 4 spare rows of the patch region,
-            // then rewrite the landed patch in place: x' = x * scale[c] + shift[c] for pixels inside the image
-            // (the zero padding of the conv applies to the NORMALISED tensor), rounded to T like a stored tensor.
-            const int cl = lane & (BK - 1);
             const int kc = (r * FK_NW + wave) * BK;
             const int d2 = p.in_stats_dil;
-            const int t2y = vt_cdiv_dev(vt_cdiv_dev(p.H, d2), FK_TH), t2x = vt_cdiv_dev(vt_cdiv_dev(p.W, d2), FK_TW);
-            const int nt = d2 * d2 * t2y * t2x;
+            const int nt = d2 * d2 * vt_cdiv_dev(vt_cdiv_dev(p.H, d2), FK_TH) * vt_cdiv_dev(vt_cdiv_dev(p.W, d2), FK_TW);
             const float* rec = p.in_tile_stats + ((size_t)img * nt * p.cin + kc + cl) * 2;
-            double sum = 0.0;
-            for (int t = 0; t < nt; ++t)
-                sum += (double)rec[(size_t)t * p.cin * 2] * (double)fk_tile_count(t, d2, t2y, t2x, p.H, p.W);
-            const double hw = (double)p.H * (double)p.W;
-            const double mean = sum / hw;
-            double m2 = 0.0;
-            for (int t = 0; t < nt; ++t) {
-                const double dm = (double)rec[(size_t)t * p.cin * 2] - mean;
-                m2 += (double)rec[(size_t)t * p.cin * 2 + 1] + (double)fk_tile_count(t, d2, t2y, t2x, p.H, p.W) * dm * dm;
+            const float* cnt = p.in_tile_stats + (size_t)p.N * nt * p.cin * 2 + (size_t)img * nt;
+            const float x0 = rec[0];
+            double s1 = 0.0, s2 = 0.0;
+            for (int t0 = 0; t0 < nt; t0 += 16) {
+                float mv[16], qv[16], cv[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int t = (t0 + k < nt) ? t0 + k : nt - 1;   // clamped: loads stay unconditional
+                    const u64v rv = *reinterpret_cast<const u64v*>(rec + (size_t)t * p.cin * 2);
+                    mv[k] = vt_u2f(rv.x);
+                    qv[k] = vt_u2f(rv.y);
+                    cv[k] = (t0 + k < nt) ? cnt[t] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const double dm = (double)mv[k] - (double)x0, n = (double)cv[k];
+                    s1 += n * dm;
+                    s2 += (cv[k] > 0.0f ? (double)qv[k] : 0.0) + n * dm * dm;
+                }
             }
-            double var = m2 / hw;   // biased, as F.instance_norm
+            const double hw = (double)p.H * (double)p.W;
+            const double mean = (double)x0 + s1 / hw;
+            double var = (s2 - s1 * s1 / hw) / hw;   // biased, as F.instance_norm
             if (var < 0.0) var = 0.0;
             const float rstd = (float)(1.0 / sqrt(var + (double)FK_IN_EPS));
             float gamma = 1.0f, beta = 0.0f;
@@ -181,10 +193,18 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
                 gamma = p.in_gb[(size_t)img * p.in_ld_gb + kc + cl];
                 beta = p.in_gb[(size_t)img * p.in_ld_gb + p.cin + kc + cl];
             }
+            ad_scale = gamma * rstd;
+            ad_shift = beta - gamma * rstd * (float)mean;
+        }
+        vt_vmcnt_fence<0>();   // patch + first weights landed (the compiler's own wait for the LDS-DMA drains both anyway)
+        if (p.in_tile_stats) {
+            // part 2: park scale / shift in the 4 spare rows of the patch region, then rewrite the landed patch in
+            // place: x' = x * scale[c] + shift[c] for pixels inside the image (the zero padding of the conv applies
+            // to the NORMALISED tensor), rounded to T like a stored tensor.
             float* tab = reinterpret_cast<float*>(my + FK_PROWS * 128);   // rows 100..103: [scale BK | shift BK]
             if (lane < BK) {
-                tab[cl] = gamma * rstd;
-                tab[BK + cl] = beta - gamma * rstd * (float)mean;
+                tab[cl] = ad_scale;
+                tab[BK + cl] = ad_shift;
             }
             vt_wave_sync();
 #pragma unroll
@@ -336,6 +356,8 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         for (int i = 0; i < 4; ++i) xs[wave * 32 + lane * 4 + i] = s4[i];
     }
     __syncthreads();
+    if (tid == 0 && tile_n == 0)     // pixel count of this tile, after the records of all images
+        p.tile_stats[(size_t)p.N * per_img * p.coutT * 2 + tile_m] = (float)tcount;
     if (tid < 8 && n < p.coutT) {   // thread c4 writes the records of channels 4*c4 .. 4*c4+3
         float* rec = p.tile_stats + ((size_t)tile_m * p.coutT + n) * 2;
 #pragma unroll

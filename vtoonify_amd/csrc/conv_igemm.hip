@@ -2073,7 +2073,8 @@ extern "C" int64_t vt_conv_weight_stream_bytes(int cout, int taps, int cin, int 
 
 extern "C" int64_t vt_conv_tile_stats_bytes(int n, int h, int w, int dil, int c) {
     if (n <= 0 || h <= 0 || w <= 0 || dil <= 0 || c <= 0) return -1;
-    return (int64_t)n * dil * dil * vt_cdiv(vt_cdiv(h, dil), FK_TH) * vt_cdiv(vt_cdiv(w, dil), FK_TW) * c * 8;
+    const int64_t tiles = (int64_t)n * dil * dil * vt_cdiv(vt_cdiv(h, dil), FK_TH) * vt_cdiv(vt_cdiv(w, dil), FK_TW);
+    return tiles * c * 8 + tiles * 4;   // {mean, M2} per (tile, channel), then the pixel count of every tile
 }
 
 extern "C" int vt_conv_weight_stream(void* out, const void* packed, int cout, int taps, int cin, int dtype,
