@@ -175,10 +175,19 @@ typedef struct vt_conv_desc {
     int32_t in_stats_dil;
     const float* in_gb;
     int32_t in_ld_gb;
+    /* Up-sampling StyledConv at the reference's MAC count (model/stylegan/model.py:273-286): up_fir != NULL makes
+     * this descriptor   out = act(upfirdn2d(conv_transpose2d(src0, W, stride 2, padding 0), up_fir, pad (1,1)) + bias) * gain
+     * with `weight` the PLAIN modulated 3x3 filters [cout][9][cin] (vt_modulate_weight with fir == NULL, tap (a, b) at
+     * a*3+b as conv_transpose2d indexes them), h x w the INPUT size and out_h = 2h, out_w = 2w.  up_fir: (4,4) fp32
+     * device taps, an outer product (make_kernel of a 1-D list, model.py:21-29).  The transposed conv runs on the
+     * matrix cores (9 MACs per input pixel instead of the 36 of the phases == 4 form), the blur on the vector
+     * ALUs out of LDS; the (2h+1)^2 intermediate never reaches HBM.  KIND 5 of vt_conv2d_tile.  kh = kw = 3,
+     * phases = 1, single source, NHWC output in the compute dtype, no residual. */
+    const float* up_fir;
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
-/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel, 4 whole-K kernel; -1: invalid descriptor).
+/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel, 4 whole-K kernel, 5 conv_transpose+blur kernel; -1: invalid descriptor).
  * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
 int vt_conv2d_tile(const vt_conv_desc* desc);
 /* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */

@@ -743,3 +743,46 @@ def test_conv_whole_k_adain_chain(dev, dtype):
     with pytest.raises(Exception, match="whole-K"):
         K.conv2d(src0=xt, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpA, cout=C, kh=3, kw=3, pad=1,
                  out=yA, ld_out=C, dtype=K.dt_code(dtype), tile_stats=ts)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_blur_kernel(dev, dtype):
+    """vt_conv_desc.up_fir: conv_transpose2d(3x3, stride 2) on the matrix cores + the 4x4 FIR blur from LDS + bias
+    + LeakyReLU in one kernel (the up-sampling StyledConv at the reference's MAC count, model.py:273-286), vs the
+    oracle's conv_transpose2d -> upfirdn2d(pad (1,1)) -> fused_leaky_relu on the same rounded operands, and vs the
+    polyphase (phases = 4) form.  Odd sizes (partial tiles, several tiles per axis), batch 2, one / several channel
+    chunks, 32- and 16-channel tiles, a cout that is not a multiple of the tile."""
+    import ctypes
+    from vtoonify_amd import _lib
+    g = np.random.default_rng(123)
+    t = F32_TOL if dtype == torch.float32 else 1.2e-2
+    unit = 32 if dtype == torch.float32 else 64
+    k1 = np.array([1, 3, 3, 1], np.float32)
+    fir = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)       # make_kernel([1,3,3,1]) * factor^2 (model.py:66,192-198)
+    for N, cin, H, W, cout, hint in [(1, unit, 5, 7, 32, 32), (2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 16),
+                                     (1, 3 * unit, 6, 15, 64, 0)]:
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)          # plain [cout][a*3+b][cin]
+        xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        z = O.conv_transpose2d(xq, wq.transpose(1, 0, 2, 3), stride=2)
+        ref = O.fused_leaky_relu(O.upfirdn2d(z, fir, pad=(1, 1)), b)
+        out = torch.zeros((N, 2 * H, 2 * W, cout), dtype=dtype, device=dev)
+        kw = dict(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
+                  bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dtype),
+                  up_fir=T(fir, dev), tile_hint=hint)
+        code = _lib.lib().vt_conv2d_tile(ctypes.byref(K.make_conv_desc(**kw)))
+        assert code // 100000000 == 5 and code % 1000 == (hint or 16), code   # few tiles: the heuristic takes 16
+        K.conv2d(**kw)
+        y = out.float().cpu().permute(0, 3, 1, 2).numpy()
+        assert tuple(y.shape) == ref.shape
+        assert rel_err(y, ref) < t, (N, cin, H, W, cout, hint)
+        # the polyphase form of the same layer (blur folded into four 3x3 filters)
+        wpp = K.modulate_weight(T(w, dev), torch.ones(cin, device=dev), 1.0, False, fir=T(fir, dev), out_dtype=dtype)
+        out2 = torch.zeros_like(out)
+        K.conv2d(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpp, cout=cout, kh=3, kw=3, pad=1,
+                 phases=4, bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out2, ld_out=cout, dtype=K.dt_code(dtype))
+        assert rel_err(y, out2.float().cpu().permute(0, 3, 1, 2).numpy()) < (t if dtype == torch.float32 else 2.5e-2)

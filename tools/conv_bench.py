@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--nosplit", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the register-staged loader")
     ap.add_argument("--nopatch", action="store_true", help="disable the patch-resident kernel")
+    ap.add_argument("--upblur", action="store_true",
+                    help="run the up-sampling convs (phases 4 rows) as conv_transpose2d + LDS blur (vt_conv_desc.up_fir)")
     ap.add_argument("--stream", action="store_true",
                     help="attach the fragment-stream weights (whole-K kernel where eligible; add --hint 400000000 to force it)")
     ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
@@ -81,10 +83,14 @@ def main():
         pad = dil * (k // 2)
         ho, wo = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
         x = torch.randn(n, h, w, cin, device=dev).to(dt)
+        upb = args.upblur and phases == 4
+        if upb:
+            phases = 1
         wt = (torch.randn(phases * cout, k * k, cin, device=dev) / (k * k * cin) ** 0.5).to(dt)
         bias = torch.randn(cout, device=dev)
+        up2 = 2 if (phases == 4 or upb) else 1
         if lay == "nhwc":
-            out = torch.empty(n, ho * (2 if phases == 4 else 1), wo * (2 if phases == 4 else 1), cout, device=dev, dtype=dt)
+            out = torch.empty(n, ho * up2, wo * up2, cout, device=dev, dtype=dt)
             kw = dict(out=out, ld_out=cout)
         else:
             out = torch.empty(n, cout, ho, wo, device=dev, dtype=torch.float32)
@@ -92,8 +98,13 @@ def main():
         d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout,
                              kh=k, kw=k, stride=stride, pad=pad, dil=dil, phases=phases, bias=bias,
                              act=K.ACT_LRELU, gain=1.414, dtype=K.dt_code(dt), tile_hint=args.hint + (1000000000 if args.generic else 0) + (200000000 if args.nopatch else 0), **kw)
+        if upb:
+            k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], device=dev)
+            firt = (torch.outer(k1, k1) / 16.0).contiguous()
+            d.up_fir = firt.data_ptr()
+            d.out_h, d.out_w = 2 * ho, 2 * wo
         wst = None
-        if args.stream and k == 3 and phases == 1:
+        if args.stream and k == 3 and phases == 1 and not upb:
             wst = K.conv_weight_stream(wt)
             if wst is not None:
                 d.weight_stream = wst.data_ptr()
@@ -120,7 +131,7 @@ def main():
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.iters
         m = n * ho * wo
-        flops = 2.0 * m * phases * cout * k * k * cin
+        flops = 2.0 * m * (4 if upb else phases) * cout * k * k * cin   # MACs of the polyphase form, for comparison
         nbytes = x.numel() * esz + wt.numel() * esz + out.numel() * out.element_size()
         tot += us
         print(f"{name:<28} tile {tile:>9d} M={m:8d} N={phases * cout:5d} K={k * k * cin:5d} {us:9.1f} us "

@@ -83,6 +83,7 @@ struct ConvArgs {
     int in_stats_dil;
     const float* in_gb;
     int in_ld_gb;
+    const float* up_fir;        // conv_transpose2d(stride 2) + blur form (conv_upblur.hpp) or NULL
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -1284,6 +1285,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 }
 
 #include "conv_fullk.hpp"
+#include "conv_upblur.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -1647,6 +1649,14 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     t.kind = 0;
     t.bm = t.bn = 0;
     t.splitk = 0;
+    if (a.up_fir) {   // conv_transpose2d + blur: its own kernel family; 16-channel tiles when 32 would leave CUs idle
+        t.kind = 5;
+        t.bm = 20 * 28;
+        const int64_t tiles = (int64_t)vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28);
+        t.bn = (hint % 1000 == 16 || (hint % 1000 != 32 && tiles * vt_cdiv(a.coutT, 32) < 256 && a.coutT >= 32)) ? 16 : 32;
+        t.splitk = 1;
+        return t;
+    }
     const int hp = (hint / 100000000) % 10;
     const int hs = (hint / 1000000) % 100, hbm = (hint / 1000) % 1000, hbn = hint % 1000;
     const int m1 = a.Ho * a.Wo;  // rows of one image
@@ -1842,6 +1852,10 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
     }
+    if (t.kind == 5) {
+        if (t.bn == 16) return launch_upblur<T, 16, 12>(a, stream);
+        return launch_upblur<T, 32, 12>(a, stream);
+    }
     if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);
         return VT_ERR_UNSUPPORTED;
@@ -1975,6 +1989,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.in_stats_dil = d->in_stats_dil > 0 ? d->in_stats_dil : 1;
     a.in_gb = d->in_gb;
     a.in_ld_gb = d->in_ld_gb;
+    a.up_fir = d->up_fir;
     a.in_scale = d->in_scale;
     a.in_shift = d->in_shift;
     a.resid = d->resid;

@@ -1,0 +1,327 @@
+// Up-sampling StyledConv in ONE kernel at the reference's MAC count: conv_transpose2d(3x3, stride 2) followed by
+// the 4x4 FIR blur (model/stylegan/model.py:273-286, Blur / upfirdn2d model.py:74-90), + bias + LeakyReLU * sqrt(2)
+// (FusedLeakyReLU of StyledConv, model.py:364-370).  Included by conv_igemm.hip inside its anonymous namespace.
+//
+// The polyphase form this replaces folds the blur into the weights: four 3x3 filters per output channel,
+// 36 MACs per input pixel and channel pair where the reference spends 9 (+ a channel-wise blur) -- the five
+// up-sampling convs of a frame issued 193 GFLOP for 48 GFLOP of algorithmic work.  Here the blur stays a
+// channel-wise stencil and runs on the vector ALUs out of LDS:
+//
+//   1. transposed conv on the matrix cores, 9 MACs: output pixel z[2I+pa, 2J+pb] of parity class (pa, pb) only
+//      receives the taps W[a][b] with a = pa (mod 2), b = pb (mod 2):  tap (a, b) reads input pixel
+//      (I - a/2, J - b/2).  So the 9 taps of W are 9 ordinary GEMM steps over a shifted input patch, each
+//      accumulating into ONE of four accumulator sets (classes) -- a "quad" (I, J) yields 2x2 z pixels.
+//      M = 16-wide rows of quads (one MFMA fragment each), N = CN output channels, K = Cin per tap; the patch of a
+//      64-channel chunk is LDS-resident for its 9 taps, the weights stream per tap through a 3-stage ring
+//      (same loader / counted-vmcnt pipeline as conv_patch_kernel).
+//   2. the z tile ((2QY-1) x 31 pixels x CN channels, compute dtype) is parked in LDS over the dead patch / ring
+//      buffers -- it never exists in HBM (134 MB fp32 per frame at the top level in the reference);
+//   3. separable 4-tap blur per channel from LDS (the FIR is an outer product, make_kernel of a 1-D list,
+//      model.py:21-29): every thread walks a column of the output tile with a sliding window of horizontally
+//      filtered rows, adds the bias, LeakyReLU * gain, and stores 16-byte NHWC vectors.
+//
+// Output tile = 2(QY-2) x 28 pixels (a 1-quad halo each side feeds the blur: 1.37x recompute at QY = 12).
+// z LDS image: 128-byte lines of LP = 128 / (CN * sizeof(T)) pixels, 16-byte slot s of line l stored at
+// s ^ (l & 7): the fragment stores of step 2 and the column reads of step 3 are spread over the banks.
+#pragma once
+
+struct UpblurArgs {
+    uint32_t nrec0, nrecw;
+    int tiles_y, tiles_x;     // output tiles per image
+};
+
+template <typename T, int CN, int QY>
+__global__ void __launch_bounds__(256)
+conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VEC = 16 / ESZ;
+    constexpr int BK = 8 * VEC;
+    constexpr int NW = 4;
+    constexpr int QX = 16, TY = 2 * (QY - 2), TX = 2 * (QX - 2);
+    constexpr int MF = QY / NW;                   // quad rows (MFMA fragments) per wave
+    constexpr int TN = CN / 16;                   // channel fragments per class
+    constexpr bool PERM = (TN % 2 == 0);
+    constexpr int PH = QY + 1, PW = QX + 1, PROWS = PH * PW;
+    constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;
+    constexpr int LB = ((CN + 7) / 8 + NW - 1) / NW;
+    constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
+    constexpr int NSTB = 3, JA = 3;
+    constexpr int ZH = 2 * QY - 1, ZW = 2 * QX - 1;
+    constexpr int PXB = CN * ESZ;                 // bytes of one z pixel
+    constexpr int LP = 128 / PXB;                 // z pixels per 128-byte line
+    constexpr int ZLINES = (ZW + LP - 1) / LP;
+    constexpr int Z_BYTES = ZH * ZLINES * 128;
+    constexpr int K_BYTES = 2 * A_BYTES + NSTB * B_BYTES;
+    constexpr int SMEM = K_BYTES > Z_BYTES ? K_BYTES : Z_BYTES;
+    static_assert(QY % NW == 0 && CN % 16 == 0 && 128 % PXB == 0, "tile shape");
+    static_assert(9 % NSTB == 0, "static ring slots");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    auto sA = [&](int b) -> unsigned char* { return smem + b * A_BYTES; };
+    auto sB = [&](int b) -> unsigned char* { return smem + 2 * A_BYTES + b * B_BYTES; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (NW - 1);
+    const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
+    const int per_img = g.tiles_y * g.tiles_x;
+    const int img = tile_m / per_img;
+    const int trem = tile_m - img * per_img;
+    const int u0 = (trem / g.tiles_x) * TY, v0 = (trem % g.tiles_x) * TX;   // first output pixel of the tile
+    const int I0 = u0 / 2, J0 = v0 / 2;
+    const int n0 = tile_n * CN;
+    const int OH = 2 * p.H, OW = 2 * p.W;
+
+    // ---- loader state: patch pixel (py, px) = input pixel (I0 - 2 + py, J0 - 2 + px) --------------------------
+    const int lrow = lane >> 3;
+    const int jj = l7 ^ lrow;
+    uint32_t pa0[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pr = (i * NW + wave) * 8 + lrow;
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = I0 - 2 + py, ix = J0 - 2 + px;
+        const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
+        pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    uint32_t woff[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int n = n0 + tile_row_channel<PERM>(row);
+        woff[i] = (row < CN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
+    const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
+    const int nchunks = p.cin / BK;
+    const int nsteps = nchunks * 9;
+
+    auto issue_a = [&](int chunk, int abuf) {
+        const uint32_t so = (uint32_t)(chunk * BK * ESZ);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) vt_glds16(r0, sA(abuf) + (i * NW + wave) * 1024, pa0[i], so);
+    };
+    auto issue_b = [&](int step, int bbuf) {
+        const int cl = step / 9, tap = step - cl * 9;
+        const uint32_t so = (uint32_t)((tap * p.cin + cl * BK) * ESZ);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) vt_glds16(rw, sB(bbuf) + (i * NW + wave) * 1024, woff[i], so);
+    };
+
+    f32x4 acc[4][MF][TN];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_a(0, 0);
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NSTB - 1; ++s)
+        if (issued < nsteps) {
+            issue_b(issued, s);
+            ++issued;
+        }
+    PatchWait<NSTB - 2, LB, PA>::run(issued - 1, false);
+    vt_lds_barrier();
+
+    int abuf = 0;
+    int a_age = 99;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = chunk * 9 + tap;
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int bbuf = tap % NSTB, nbbuf = (tap + NSTB - 1) % NSTB;
+            if (issued < nsteps) {
+                issue_b(issued, nbbuf);
+                ++issued;
+            }
+            if (tap == JA && chunk + 1 < nchunks) {
+                issue_a(chunk + 1, abuf ^ 1);
+                a_age = 0;
+            }
+            const int ta = tap / 3, tb = tap - ta * 3;
+            const int di = ta >> 1, dj = tb >> 1, cls = (ta & 1) * 2 + (tb & 1);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int slot = sub * 4 + q;
+                u128 fa[MF], fb[TN];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    const int pr = (wave * MF + m + 1 - di) * PW + (1 - dj) + l15;
+                    fa[m] = ld128(sA(abuf) + pr * 128 + ((slot ^ (pr & 7)) << 4));
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) fb[n] = ld128(sB(bbuf) + (n * 16 + l15) * 128 + ((slot ^ l7) << 4));
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) Mma<T>::run(acc[cls][m][n], fb[n], fa[m]);
+            }
+            PatchWait<NSTB - 2, LB, PA>::run(issued - 2 - s, a_age <= 1);
+            vt_lds_barrier();
+            if (a_age < 99) ++a_age;
+        }
+        abuf ^= 1;
+        a_age = 99;
+    }
+    __syncthreads();   // patch / ring buffers are dead: the z tile goes over them
+
+    // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile -----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int zpa = c >> 1, zpb = c & 1;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+            const int zy = 2 * (wave * MF + m) + zpa - 1, zx = 2 * l15 + zpb - 1;
+            if (zy < 0 || zx < 0) continue;
+            const int line = zx / LP, subp = zx - line * LP;
+            unsigned char* zl = smem + (zy * ZLINES + line) * 128;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int ch = frag_channel<PERM>(n, q);                // first of this lane's 4 channels
+                const int b0 = subp * PXB + ch * ESZ;                   // byte offset inside the line
+                const int phys = ((b0 >> 4) ^ (line & 7)) << 4;
+                float f[4] = {acc[c][m][n][0], acc[c][m][n][1], acc[c][m][n][2], acc[c][m][n][3]};
+                if (ESZ == 2) {
+                    u64v v;
+                    v.x = pack_bf16x2(f[0], f[1]);
+                    v.y = pack_bf16x2(f[2], f[3]);
+                    *reinterpret_cast<u64v*>(zl + phys + (b0 & 15)) = v;
+                } else {
+                    st128(zl + phys, pack16<float>(f));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
+    // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1) ---------
+    constexpr int NV = CN / VEC;                 // 16-byte channel vectors per pixel
+    constexpr int GROUPS = 256 / (TX * NV) >= 1 ? 256 / (TX * NV) : 1;
+    constexpr int ROWS = (TY + GROUPS - 1) / GROUPS;
+    static_assert(TX * NV <= 256, "one thread per (column, channel vector)");
+    const float* fir = p.up_fir;
+    float kx[4], ky[4], ksum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kx[i] = ky[i] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float t = fir[(3 - a) * 4 + (3 - b)];   // upfirdn2d applies the flipped kernel
+            ky[a] += t;
+            kx[b] += t;
+            ksum += t;
+        }
+    const float inv = 1.0f / ksum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ky[i] *= inv;
+    const int qv = tid % NV, col = (tid / NV) % TX, grp = tid / (NV * TX);
+    if (grp >= GROUPS) return;
+    const int ov = v0 + col;
+    const int nch = n0 + qv * VEC;
+    float bv[VEC], sv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const int nn = nch + k;
+        bv[k] = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
+        sv[k] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
+    }
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    // byte address of z pixel (zy, zx), channel vector qv
+    auto zaddr = [&](int zy, int zx) -> const unsigned char* {
+        const int line = zx / LP, subp = zx - line * LP;
+        const int s = (subp * PXB + qv * 16) >> 4;
+        return smem + (zy * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
+    };
+    auto hrow = [&](int zy, float* h) {   // horizontally filtered z row zy at this thread's column
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) h[k] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float f[VEC];
+            unpack16<T>(ld128(zaddr(zy, col + t)), f);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) h[k] += f[k] * kx[t];
+        }
+    };
+    const int r0w = grp * ROWS;
+    float hb[4][VEC];
+    hrow(r0w + 0, hb[0]);
+    hrow(r0w + 1, hb[1]);
+    hrow(r0w + 2, hb[2]);
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+        const int u = r0w + rr;
+        if (u >= TY) break;
+        hrow(u + 3, hb[(rr + 3) & 3]);
+        const int ou = u0 + u;
+        if (ou >= OH || ov >= OW || nch >= p.coutT) continue;
+        float f[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float v = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v += hb[(rr + t) & 3][k] * ky[t];
+            f[k] = conv_finish(p, v, bv[k], ga, sv[k]);
+        }
+        const int64_t opix = ((int64_t)img * OH + ou) * OW + ov;
+        T* o = (T*)p.out + opix * p.ld_out + nch;
+        if (nch + VEC <= p.coutT) {
+            st128(o, pack16<T>(f));
+        } else {
+            for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+        }
+    }
+}
+
+template <typename T>
+static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BK = 8 * (16 / ESZ);
+    if (!a.up_fir || a.transposed || a.in_scale || a.rgb_w || a.resid || a.c1 != 0 || a.post_relu) return false;
+    if (a.taps != 9 || a.kw != 3 || a.phases != 1 || a.Ho != 2 * a.H || a.Wo != 2 * a.W) return false;
+    if (a.cin % BK != 0 || a.coutT % 8 != 0) return false;
+    if (a.out_layout != VT_OUT_NHWC || a.out_f32 != (ESZ == 4) || !a.vec_store) return false;
+    const int64_t lim = ((int64_t)1 << 31) - 4096;
+    const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * ESZ, nw = (int64_t)a.coutT * a.K * ESZ;
+    if (n0 >= lim || nw >= lim) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrecw = (uint32_t)nw;
+    g.tiles_y = vt_cdiv(2 * a.H, ty);
+    g.tiles_x = vt_cdiv(2 * a.W, tx);
+    return true;
+}
+
+template <typename T, int CN, int QY>
+int launch_upblur(const ConvArgs& a, vt_stream stream) {
+    UpblurArgs g;
+    if (!upblur_eligible<T>(a, g, 2 * (QY - 2), 28)) {
+        vt_set_error("vt_conv2d: up_fir (conv_transpose + blur) form not supported for this convolution");
+        return VT_ERR_UNSUPPORTED;
+    }
+    ConvArgs args = a;
+    args.splitk = 1;
+    args.kps = 0;
+    args.slab_perm = 0;
+    args.tiles_n = vt_cdiv(a.coutT, CN);
+    args.tiles_m = a.N * g.tiles_y * g.tiles_x;
+    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n;
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    auto k = conv_upblur_kernel<T, CN, QY>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    return vt_check_launch("vt_conv2d(upblur)");
+}

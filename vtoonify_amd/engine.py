@@ -84,6 +84,9 @@ class VToonifyEngine:
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
         self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
+        # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
+        # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
+        self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
         # per-layer plan overrides {conv_signature(desc): vt_conv_desc.tile_hint}: lets a measured table
         # (tools/plan_sweep.py) pick tile / split-K / kernel family per conv geometry without a rebuild.
         # Like the built-in heuristics the key never contains the batch, so frames stay batch-invariant.
@@ -139,6 +142,11 @@ class VToonifyEngine:
             self.w[f"to_rgbs.{i}.bias"] = sd[f"{self.g}to_rgbs.{i}.bias"].reshape(3).contiguous()
         self.fir_up = sd[f"{self.g}convs.6.conv.blur.kernel"].contiguous()
         self.fir_rgb = sd[f"{self.g}to_rgbs.3.upsample.kernel"].contiguous()
+        if self.use_upblur:   # the LDS blur is separable: the FIR must be an outer product (make_kernel of a 1-D list)
+            k = self.fir_up.detach().float().cpu()
+            if not (k.shape == (4, 4) and float(k.sum()) != 0.0 and
+                    torch.allclose(torch.outer(k.sum(1), k.sum(0)) / k.sum(), k, rtol=1e-5, atol=1e-7)):
+                self.use_upblur = False
         # fragment-stream images of the static 3x3 weights (vt_conv_weight_stream): lets vt_conv2d run the
         # few-pixel / wide-channel layers (the H/8 x W/8 trunk) on the whole-K kernel -- no split-K slabs
         self._wstream: Dict[int, torch.Tensor] = {}
@@ -160,7 +168,7 @@ class VToonifyEngine:
     def conv_signature(d) -> str:
         """Geometry key of a conv launch (no batch): 'HxW:cin->cout_total:k3s1d1p1[:nchw]'."""
         return (f"{d.h}x{d.w}:{d.c0 + d.c1}->{d.cout * d.phases}:k{d.kh}s{d.stride}d{d.dil}p{d.phases}"
-                + (":nchw" if d.out_layout == OUT_NCHW else ""))
+                + (":nchw" if d.out_layout == OUT_NCHW else "") + (":up" if d.up_fir else ""))
 
     def _apply_hint(self, d):
         h = self.tile_hints.get(self.conv_signature(d))
@@ -283,7 +291,7 @@ class VToonifyEngine:
                 lin(1, s, cin, ada.data_ptr() + lat * 512 * 4, N_LATENT * 512,
                     sd[f"{g}{name}.conv.modulation.weight"], sd[f"{g}{name}.conv.modulation.bias"],
                     ns, 1.0 / math.sqrt(512), 1.0)
-                phases = 4 if up else 1
+                phases = 4 if (up and not self.use_upblur) else 1
                 taps = 9 if up else k * k
                 wm = self._buf(plan, f"wm.{name}", (ns, phases * cout, taps, cin))
                 plan.modw[name] = wm
@@ -291,7 +299,7 @@ class VToonifyEngine:
                     it = _lib.ModulateItem()
                     it.out = wm.data_ptr() + b * phases * cout * taps * cin * self.esz
                     it.weight, it.s = w.data_ptr(), s.data_ptr() + b * cin * 4
-                    it.fir = self.fir_up.data_ptr() if up else None
+                    it.fir = self.fir_up.data_ptr() if (up and not self.use_upblur) else None
                     it.cout, it.cin, it.k, it.demodulate = cout, cin, k, int(demod)
                     it.scale = 1.0 / math.sqrt(cin * k * k)
                     mods.append(it)
@@ -557,10 +565,17 @@ class VToonifyEngine:
                 # StyledConv(upsample): polyphase 3x3 with 4*Cout filters + pixel shuffle.
                 # Algorithmic MACs = the reference's conv_transpose2d (9 per in-pixel) + 4x4 blur
                 # (16 per out element), not the 36 per in-pixel the polyphase form spends.
-                self._op_conv(ops, plan, ref_macs=nb * hw * co * c1o * 9 + nb * 4 * hw * c1o * 16, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co, ld0=co, n=nb, h=h,
-                              w=w, out_h=h, out_w=w, weight=wm1, cout=c1o, kh=3, kw=3, pad=1, phases=4,
-                              bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
-                              out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
+                ref_macs = nb * hw * co * c1o * 9 + nb * 4 * hw * c1o * 16
+                if self.use_upblur:   # conv_transpose2d on the matrix cores + the FIR blur out of LDS, one kernel
+                    self._op_conv(ops, plan, ref_macs=ref_macs, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co,
+                                  ld0=co, n=nb, h=h, w=w, out_h=2 * h, out_w=2 * w, weight=wm1, cout=c1o, kh=3, kw=3,
+                                  up_fir=self.fir_up, bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
+                                  out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
+                else:
+                    self._op_conv(ops, plan, ref_macs=ref_macs, src0=out.data_ptr() + b0 * hw * co * self.esz, c0=co,
+                                  ld0=co, n=nb, h=h, w=w, out_h=h, out_w=w, weight=wm1, cout=c1o, kh=3, kw=3, pad=1,
+                                  phases=4, bias=sd[f"{g}{n1}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
+                                  out=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, ld_out=c1o)
                 same_kw = dict(src0=up.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
                                h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm2, cout=c1o, kh=3, kw=3, pad=1,
                                bias=sd[f"{g}{n2}.activate.bias"], act=ACT_LRELU, gain=SQRT2,
@@ -607,7 +622,7 @@ class VToonifyEngine:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
             kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
-                     3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel"}[kind]
+                     3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel", 5: "conv_upblur_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1:
