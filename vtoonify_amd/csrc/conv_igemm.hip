@@ -1853,8 +1853,11 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         return VT_ERR_UNSUPPORTED;
     }
     if (t.kind == 5) {
-        if (t.bn == 16) return launch_upblur<T, 16, 12>(a, stream);
-        return launch_upblur<T, 32, 12>(a, stream);
+        // deep layers (>= 4 channel chunks): double-buffered chunks, one workgroup per CU; shallow ones: single
+        // stage, two workgroups per CU
+        const bool db = a.cin / (8 * (16 / (int)sizeof(T))) >= 4;
+        if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1>(a, stream) : launch_upblur<T, 16, 12, 0>(a, stream);
+        return db ? launch_upblur<T, 32, 12, 1>(a, stream) : launch_upblur<T, 32, 12, 0>(a, stream);
     }
     if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);

@@ -30,7 +30,7 @@ struct UpblurArgs {
     int tiles_y, tiles_x;     // output tiles per image
 };
 
-template <typename T, int CN, int QY>
+template <typename T, int CN, int QY, int DB>
 __global__ void __launch_bounds__(256)
 conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ESZ = (int)sizeof(T);
@@ -42,24 +42,25 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int TN = CN / 16;                   // channel fragments per class
     constexpr bool PERM = (TN % 2 == 0);
     constexpr int PH = QY + 1, PW = QX + 1, PROWS = PH * PW;
-    constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;
-    constexpr int LB = ((CN + 7) / 8 + NW - 1) / NW;
-    constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
-    constexpr int NSTB = 3, JA = 3;
+    constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;      // patch loads per wave per chunk
+    constexpr int WROWS = 9 * CN;                            // weight rows of a chunk: [tap][channel]
+    constexpr int LBC = (WROWS / 8 + NW - 1) / NW;           // weight loads per wave per chunk
+    constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LBC * NW * 1024;
+    constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int ZH = 2 * QY - 1, ZW = 2 * QX - 1;
     constexpr int PXB = CN * ESZ;                 // bytes of one z pixel
     constexpr int LP = 128 / PXB;                 // z pixels per 128-byte line
     constexpr int ZLINES = (ZW + LP - 1) / LP;
     constexpr int Z_BYTES = ZH * ZLINES * 128;
-    constexpr int K_BYTES = 2 * A_BYTES + NSTB * B_BYTES;
+    constexpr int K_BYTES = (DB ? 2 : 1) * STAGE;
     constexpr int SMEM = K_BYTES > Z_BYTES ? K_BYTES : Z_BYTES;
-    static_assert(QY % NW == 0 && CN % 16 == 0 && 128 % PXB == 0, "tile shape");
-    static_assert(9 % NSTB == 0, "static ring slots");
+    static_assert(QY % NW == 0 && CN % 16 == 0 && 128 % PXB == 0 && CN % 8 == 0, "tile shape");
     static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(PA + LBC < 64, "vmcnt is 6 bits");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
-    auto sA = [&](int b) -> unsigned char* { return smem + b * A_BYTES; };
-    auto sB = [&](int b) -> unsigned char* { return smem + 2 * A_BYTES + b * B_BYTES; };
+    auto sA = [&](int b) -> unsigned char* { return smem + b * STAGE; };
+    auto sB = [&](int b) -> unsigned char* { return smem + b * STAGE + A_BYTES; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,28 +89,31 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
         pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
     }
-    uint32_t woff[LB];
+    // weights of a chunk: LDS row t*CN + r = tap t, tile row r (fragment order, see tile_row_channel)
+    uint32_t woff[LBC];
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
+    for (int i = 0; i < LBC; ++i) {
         const int row = (i * NW + wave) * 8 + lrow;
-        const int n = n0 + tile_row_channel<PERM>(row);
-        woff[i] = (row < CN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+        const int tap = row / CN, r = row - tap * CN;
+        const int n = n0 + tile_row_channel<PERM>(r);
+        woff[i] = (row < WROWS && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + (uint32_t)(tap * p.cin * ESZ) + jj * 16
+                                                : GLDS_OOB;
     }
     const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
     const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
     const int nchunks = p.cin / BK;
-    const int nsteps = nchunks * 9;
 
-    auto issue_a = [&](int chunk, int abuf) {
+    // one chunk = BK input channels: its patch AND all 9 taps of its weights are LDS-resident, so the 9 taps run
+    // without a barrier (a 3-stage per-tap weight ring measured ~1 us per tap step: two taps in flight do not
+    // cover the L2 latency).  DB: the next chunk loads into the other stage while this one computes (one
+    // workgroup per CU, the deep layers); !DB: single stage, two workgroups per CU cover each other's loads
+    // and blur phases (the 64/128-channel levels).
+    auto issue = [&](int chunk, int st) {
         const uint32_t so = (uint32_t)(chunk * BK * ESZ);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) vt_glds16(r0, sA(abuf) + (i * NW + wave) * 1024, pa0[i], so);
-    };
-    auto issue_b = [&](int step, int bbuf) {
-        const int cl = step / 9, tap = step - cl * 9;
-        const uint32_t so = (uint32_t)((tap * p.cin + cl * BK) * ESZ);
+        for (int i = 0; i < PA; ++i) vt_glds16(r0, sA(st) + (i * NW + wave) * 1024, pa0[i], so);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) vt_glds16(rw, sB(bbuf) + (i * NW + wave) * 1024, woff[i], so);
+        for (int i = 0; i < LBC; ++i) vt_glds16(rw, sB(st) + (i * NW + wave) * 1024, woff[i], so);
     };
 
     f32x4 acc[4][MF][TN];
@@ -120,58 +124,53 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 #pragma unroll
             for (int n = 0; n < TN; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_a(0, 0);
-    int issued = 0;
-#pragma unroll
-    for (int s = 0; s < NSTB - 1; ++s)
-        if (issued < nsteps) {
-            issue_b(issued, s);
-            ++issued;
-        }
-    PatchWait<NSTB - 2, LB, PA>::run(issued - 1, false);
-    vt_lds_barrier();
-
-    int abuf = 0;
-    int a_age = 99;
+    issue(0, 0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int st = DB ? (chunk & 1) : 0;
+        if (DB) {
+            // stage st^1 was read by chunk - 1: every wave is past it once it has reached this barrier
+            vt_glds_wait_n<0>();
+            vt_lds_barrier();
+            if (chunk + 1 < nchunks) issue(chunk + 1, st ^ 1);
+        } else {
+            vt_glds_wait_n<0>();
+            vt_lds_barrier();
+        }
+        const unsigned char* pa = sA(st);
+        const unsigned char* pb = sB(st);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int s = chunk * 9 + tap;
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int bbuf = tap % NSTB, nbbuf = (tap + NSTB - 1) % NSTB;
-            if (issued < nsteps) {
-                issue_b(issued, nbbuf);
-                ++issued;
-            }
-            if (tap == JA && chunk + 1 < nchunks) {
-                issue_a(chunk + 1, abuf ^ 1);
-                a_age = 0;
-            }
-            const int ta = tap / 3, tb = tap - ta * 3;
-            const int di = ta >> 1, dj = tb >> 1, cls = (ta & 1) * 2 + (tb & 1);
+        for (int sub = 0; sub < 2; ++sub) {
+            const int slot = sub * 4 + q;
+            // taps grouped by input shift (a/2, b/2): the four taps (0|1, 0|1) share one set of pixel fragments
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int slot = sub * 4 + q;
-                u128 fa[MF], fb[TN];
+            for (int sh = 0; sh < 4; ++sh) {
+                const int di = sh >> 1, dj = sh & 1;
+                u128 fa[MF];
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {
                     const int pr = (wave * MF + m + 1 - di) * PW + (1 - dj) + l15;
-                    fa[m] = ld128(sA(abuf) + pr * 128 + ((slot ^ (pr & 7)) << 4));
+                    fa[m] = ld128(pa + pr * 128 + ((slot ^ (pr & 7)) << 4));
                 }
 #pragma unroll
-                for (int n = 0; n < TN; ++n) fb[n] = ld128(sB(bbuf) + (n * 16 + l15) * 128 + ((slot ^ l7) << 4));
+                for (int ta = 2 * di; ta < (di ? 3 : 2); ++ta)
 #pragma unroll
-                for (int m = 0; m < MF; ++m)
+                    for (int tb = 2 * dj; tb < (dj ? 3 : 2); ++tb) {
+                        const int tap = ta * 3 + tb, cls = (ta & 1) * 2 + (tb & 1);
+                        u128 fb[TN];
 #pragma unroll
-                    for (int n = 0; n < TN; ++n) Mma<T>::run(acc[cls][m][n], fb[n], fa[m]);
+                        for (int n = 0; n < TN; ++n)
+                            fb[n] = ld128(pb + (tap * CN + n * 16 + l15) * 128 + ((slot ^ l7) << 4));
+#pragma unroll
+                        for (int m = 0; m < MF; ++m)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n) Mma<T>::run(acc[cls][m][n], fb[n], fa[m]);
+                    }
             }
-            PatchWait<NSTB - 2, LB, PA>::run(issued - 2 - s, a_age <= 1);
-            vt_lds_barrier();
-            if (a_age < 99) ++a_age;
         }
-        abuf ^= 1;
-        a_age = 99;
+        if (!DB && chunk + 1 < nchunks) {
+            vt_lds_barrier();   // every wave is done reading the stage
+            issue(chunk + 1, 0);
+        }
     }
     __syncthreads();   // patch / ring buffers are dead: the z tile goes over them
 
@@ -303,7 +302,7 @@ static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
     return true;
 }
 
-template <typename T, int CN, int QY>
+template <typename T, int CN, int QY, int DB>
 int launch_upblur(const ConvArgs& a, vt_stream stream) {
     UpblurArgs g;
     if (!upblur_eligible<T>(a, g, 2 * (QY - 2), 28)) {
@@ -321,7 +320,7 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    auto k = conv_upblur_kernel<T, CN, QY>;
+    auto k = conv_upblur_kernel<T, CN, QY, DB>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
     return vt_check_launch("vt_conv2d(upblur)");
 }
