@@ -138,6 +138,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         }
         const unsigned char* pa = sA(st);
         const unsigned char* pb = sB(st);
+        if (p.dbg == 12) continue;   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): loads only
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int slot = sub * 4 + q;
@@ -173,6 +174,14 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         }
     }
     __syncthreads();   // patch / ring buffers are dead: the z tile goes over them
+    if (p.dbg == 11 || p.dbg == 12) {   // ablation: no z tile, no blur, no store
+        float sacc = 0.f;
+        for (int c = 0; c < 4; ++c)
+            for (int m = 0; m < MF; ++m)
+                for (int n = 0; n < TN; ++n) sacc += acc[c][m][n][0] + acc[c][m][n][1] + acc[c][m][n][2] + acc[c][m][n][3];
+        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
+        return;
+    }
 
     // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile -----
 #pragma unroll
@@ -204,11 +213,14 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     __syncthreads();
 
     // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
-    // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1) ---------
+    // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
+    // This phase is pure vector-ALU work (measured 70 % of the kernel before it was trimmed): explicit fmaf
+    // (the build runs -ffp-contract=off), branch-free rows, addresses as one register per tap + immediates,
+    // bias folded into the vertical sum, activation as one select.
     constexpr int NV = CN / VEC;                 // 16-byte channel vectors per pixel
     constexpr int GROUPS = 256 / (TX * NV) >= 1 ? 256 / (TX * NV) : 1;
-    constexpr int ROWS = (TY + GROUPS - 1) / GROUPS;
-    static_assert(TX * NV <= 256, "one thread per (column, channel vector)");
+    constexpr int ROWS = TY / GROUPS;
+    static_assert(TX * NV <= 256 && TY % GROUPS == 0, "one thread per (column, channel vector, row group)");
     const float* fir = p.up_fir;
     float kx[4], ky[4], ksum = 0.0f;
 #pragma unroll
@@ -229,57 +241,58 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     if (grp >= GROUPS) return;
     const int ov = v0 + col;
     const int nch = n0 + qv * VEC;
-    float bv[VEC], sv[VEC];
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    float bv[VEC], gpos[VEC], gneg[VEC];   // act(v) * gain = v * (v > 0 ? gpos : gneg)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const int nn = nch + k;
         bv[k] = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
-        sv[k] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
+        const float sl = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
+        gpos[k] = ga;
+        gneg[k] = (p.act == VT_ACT_LRELU) ? ga * sl : ga;
     }
-    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
-    // byte address of z pixel (zy, zx), channel vector qv
-    auto zaddr = [&](int zy, int zx) -> const unsigned char* {
+    const int r0w = grp * ROWS;
+    // byte address of z pixel (row r0w, column col + t), channel vector qv: one register per tap, rows by immediates
+    const unsigned char* zt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int zx = col + t;
         const int line = zx / LP, subp = zx - line * LP;
         const int s = (subp * PXB + qv * 16) >> 4;
-        return smem + (zy * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
-    };
-    auto hrow = [&](int zy, float* h) {   // horizontally filtered z row zy at this thread's column
+        zt[t] = smem + (r0w * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
+    }
+    float hb[4][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) h[k] = 0.0f;
+    for (int rr = 0; rr < ROWS + 3; ++rr) {
+        // horizontally filtered z row r0w + rr -> window slot rr & 3
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float f[VEC];
-            unpack16<T>(ld128(zaddr(zy, col + t)), f);
+            unpack16<T>(ld128(zt[t] + rr * (ZLINES * 128)), f);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) h[k] += f[k] * kx[t];
+            for (int k = 0; k < VEC; ++k) hb[rr & 3][k] = (t == 0) ? f[k] * kx[0] : fmaf(f[k], kx[t], hb[rr & 3][k]);
         }
-    };
-    const int r0w = grp * ROWS;
-    float hb[4][VEC];
-    hrow(r0w + 0, hb[0]);
-    hrow(r0w + 1, hb[1]);
-    hrow(r0w + 2, hb[2]);
-#pragma unroll
-    for (int rr = 0; rr < ROWS; ++rr) {
-        const int u = r0w + rr;
-        if (u >= TY) break;
-        hrow(u + 3, hb[(rr + 3) & 3]);
-        const int ou = u0 + u;
-        if (ou >= OH || ov >= OW || nch >= p.coutT) continue;
+        if (rr < 3) continue;
+        const int u = r0w + rr - 3;          // output row of the tile: window rows u .. u+3
         float f[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float v = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v += hb[(rr + t) & 3][k] * ky[t];
-            f[k] = conv_finish(p, v, bv[k], ga, sv[k]);
+            float v = fmaf(hb[(rr - 3) & 3][k], ky[0], bv[k]);
+            v = fmaf(hb[(rr - 2) & 3][k], ky[1], v);
+            v = fmaf(hb[(rr - 1) & 3][k], ky[2], v);
+            v = fmaf(hb[rr & 3][k], ky[3], v);
+            f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
         }
+        const int ou = u0 + u;
         const int64_t opix = ((int64_t)img * OH + ou) * OW + ov;
         T* o = (T*)p.out + opix * p.ld_out + nch;
-        if (nch + VEC <= p.coutT) {
-            st128(o, pack16<T>(f));
-        } else {
-            for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+        if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
+        if (ou < OH && ov < OW) {
+            if (nch + VEC <= p.coutT) {
+                st128(o, pack16<T>(f));
+            } else {
+                for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+            }
         }
     }
 }
@@ -291,6 +304,7 @@ static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
     if (!a.up_fir || a.transposed || a.in_scale || a.rgb_w || a.resid || a.c1 != 0 || a.post_relu) return false;
     if (a.taps != 9 || a.kw != 3 || a.phases != 1 || a.Ho != 2 * a.H || a.Wo != 2 * a.W) return false;
     if (a.cin % BK != 0 || a.coutT % 8 != 0) return false;
+    if (a.act != VT_ACT_NONE && a.act != VT_ACT_LRELU) return false;
     if (a.out_layout != VT_OUT_NHWC || a.out_f32 != (ESZ == 4) || !a.vec_store) return false;
     const int64_t lim = ((int64_t)1 << 31) - 4096;
     const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * ESZ, nw = (int64_t)a.coutT * a.K * ESZ;
