@@ -31,7 +31,7 @@ struct UpblurArgs {
 };
 
 template <typename T, int CN, int QY, int DB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // two 4-wave workgroups per CU: <= 256 registers (VGPR + AGPR) per lane
 conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VEC = 16 / ESZ;
@@ -212,6 +212,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     }
     __syncthreads();
 
+    if (p.dbg == 14) return;   // ablation: stop after the z tile
     // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
     // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
     // This phase is pure vector-ALU work (measured 70 % of the kernel before it was trimmed): explicit fmaf
@@ -261,37 +262,65 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         const int s = (subp * PXB + qv * 16) >> 4;
         zt[t] = smem + (r0w * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
     }
-    float hb[4][VEC];
+    // Row rr of the horizontally filtered tile feeds the four output rows rr-3 .. rr: four running sums per
+    // channel (ring slot = output row & 3), so no arithmetic chain is longer than three dependent operations
+    // (dependent v_pk_fma chains ran at 5-6 cycles per instruction with one or two waves per SIMD).  The row
+    // loop is a REAL loop of 4-row bodies (static ring slots inside): fully unrolled the compiler hoisted every
+    // LDS read and needed 472 registers.
+    float osum[4][VEC];
 #pragma unroll
-    for (int rr = 0; rr < ROWS + 3; ++rr) {
-        // horizontally filtered z row r0w + rr -> window slot rr & 3
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float f[VEC];
-            unpack16<T>(ld128(zt[t] + rr * (ZLINES * 128)), f);
+        for (int k = 0; k < VEC; ++k) osum[j][k] = 0.0f;
+    T* orow = (T*)p.out + (((int64_t)img * OH + u0 + r0w) * OW + ov) * p.ld_out + nch;   // output row r0w of this thread
+    const int64_t ostep = (int64_t)OW * p.ld_out;
+    const bool full = nch + VEC <= p.coutT;
+    const bool colok = ov < OW;
+    constexpr int NIT = (ROWS + 3 + 3) / 4;
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        const int zoff = it * 4 * (ZLINES * 128);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) hb[rr & 3][k] = (t == 0) ? f[k] * kx[0] : fmaf(f[k], kx[t], hb[rr & 3][k]);
-        }
-        if (rr < 3) continue;
-        const int u = r0w + rr - 3;          // output row of the tile: window rows u .. u+3
-        float f[VEC];
+        for (int j = 0; j < 4; ++j) {
+            const int rr = it * 4 + j;
+            if (rr >= ROWS + 3) break;   // uniform
+            float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
+            if (p.dbg == 16) {   // ablation: no LDS reads in the blur
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float v = fmaf(hb[(rr - 3) & 3][k], ky[0], bv[k]);
-            v = fmaf(hb[(rr - 2) & 3][k], ky[1], v);
-            v = fmaf(hb[(rr - 1) & 3][k], ky[2], v);
-            v = fmaf(hb[rr & 3][k], ky[3], v);
-            f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
-        }
-        const int ou = u0 + u;
-        const int64_t opix = ((int64_t)img * OH + ou) * OW + ov;
-        T* o = (T*)p.out + opix * p.ld_out + nch;
-        if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
-        if (ou < OH && ov < OW) {
-            if (nch + VEC <= p.coutT) {
-                st128(o, pack16<T>(f));
+                for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
             } else {
-                for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+                unpack16<T>(ld128(zt[0] + zoff + j * (ZLINES * 128)), f0);
+                unpack16<T>(ld128(zt[1] + zoff + j * (ZLINES * 128)), f1);
+                unpack16<T>(ld128(zt[2] + zoff + j * (ZLINES * 128)), f2);
+                unpack16<T>(ld128(zt[3] + zoff + j * (ZLINES * 128)), f3);
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
+            // output row rr - t takes this row with vertical tap t; its sum lives in slot (j - t) & 3.  Rows
+            // outside 0..ROWS-1 only ever touch slots that are re-initialised (t == 0) before they are stored.
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                osum[(j + 3) & 3][k] = fmaf(h[k], ky[1], osum[(j + 3) & 3][k]);
+                osum[(j + 2) & 3][k] = fmaf(h[k], ky[2], osum[(j + 2) & 3][k]);
+                osum[(j + 1) & 3][k] = fmaf(h[k], ky[3], osum[(j + 1) & 3][k]);
+                osum[j][k] = fmaf(h[k], ky[0], bv[k]);
+            }
+            const int u = rr - 3;            // finished: rows u .. u+3 have all been added to slot (j + 1) & 3
+            if (u < 0 || u >= ROWS) continue;   // uniform
+            float f[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float v = osum[(j + 1) & 3][k];
+                f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
+            }
+            T* o = orow + u * ostep;
+            if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
+            if (u0 + r0w + u < OH && colok) {
+                if (full) {
+                    st128(o, pack16<T>(f));
+                } else {
+                    for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+                }
             }
         }
     }
