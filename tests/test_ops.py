@@ -746,6 +746,32 @@ def test_conv_whole_k_adain_chain(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_blur_persistent_form(dev, dtype, monkeypatch):
+    """Single-chunk layers with many tiles (the 1024^2 level) run persistent workgroups: weights resident in LDS,
+    next tile's patch prefetched during the blur.  Forced here on a small image (3 workgroups walk 12 tiles, a
+    ragged last round) and compared bit-for-bit with the one-tile-per-workgroup form."""
+    g = np.random.default_rng(5)
+    cin = 32 if dtype == torch.float32 else 64
+    N, H, W, cout = 2, 21, 19, 32
+    x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+    w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    k1 = np.array([1, 3, 3, 1], np.float32)
+    fir = T((np.outer(k1, k1) / 16.0).astype(np.float32), dev)
+    xt = K.nchw_to_nhwc(T(x, dev), dtype)
+    wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+    outs = []
+    for persist in ("0", "1"):
+        monkeypatch.setenv("VT_UPBLUR_PERSIST", persist)
+        monkeypatch.setenv("VT_UPBLUR_WGS", "5")
+        out = torch.zeros((N, 2 * H, 2 * W, cout), dtype=dtype, device=dev)
+        K.conv2d(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
+                 bias=T(g.standard_normal(cout).astype(np.float32) * 0 + 0.1, dev), act=K.ACT_LRELU, gain=2 ** 0.5,
+                 out=out, ld_out=cout, dtype=K.dt_code(dtype), up_fir=fir, tile_hint=32)
+        outs.append(out.float().cpu().numpy())
+    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose_blur_kernel(dev, dtype):
     """vt_conv_desc.up_fir: conv_transpose2d(3x3, stride 2) on the matrix cores + the 4x4 FIR blur from LDS + bias
     + LeakyReLU in one kernel (the up-sampling StyledConv at the reference's MAC count, model.py:273-286), vs the

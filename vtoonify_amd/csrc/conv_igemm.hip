@@ -1855,9 +1855,17 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
     if (t.kind == 5) {
         // deep layers (>= 4 channel chunks): double-buffered chunks, one workgroup per CU; shallow ones: single
         // stage, two workgroups per CU
-        const bool db = a.cin / (8 * (16 / (int)sizeof(T))) >= 4;
-        if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1>(a, stream) : launch_upblur<T, 16, 12, 0>(a, stream);
-        return db ? launch_upblur<T, 32, 12, 1>(a, stream) : launch_upblur<T, 32, 12, 0>(a, stream);
+        const int chunks = a.cin / (8 * (16 / (int)sizeof(T)));
+        const bool db = chunks >= 4;
+        // single-chunk layers with many tiles per CU (the 1024^2 level): persistent workgroups, resident weights.
+        // VT_UPBLUR_PERSIST = minimum number of workgroups for the persistent form (0 = never; tests use 1)
+        const char* pe = getenv("VT_UPBLUR_PERSIST");
+        const int64_t persist_min = pe ? atoll(pe) : 512;
+        const int64_t tiles = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28);
+        if (t.bn == 32 && chunks == 1 && persist_min > 0 && tiles * vt_cdiv(a.coutT, 32) >= persist_min)
+            return launch_upblur<T, 32, 12, 0, 1>(a, stream);
+        if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1, 0>(a, stream) : launch_upblur<T, 16, 12, 0, 0>(a, stream);
+        return db ? launch_upblur<T, 32, 12, 1, 0>(a, stream) : launch_upblur<T, 32, 12, 0, 0>(a, stream);
     }
     if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);

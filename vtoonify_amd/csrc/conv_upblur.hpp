@@ -30,8 +30,8 @@ struct UpblurArgs {
     int tiles_y, tiles_x;     // output tiles per image
 };
 
-template <typename T, int CN, int QY, int DB>
-__global__ void __launch_bounds__(256, 2)   // two 4-wave workgroups per CU: <= 256 registers (VGPR + AGPR) per lane
+template <typename T, int CN, int QY, int DB, int PERSIST>
+__global__ void __launch_bounds__(256, PERSIST ? 1 : 2)   // !PERSIST: two 4-wave workgroups per CU (<= 256 registers)
 conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VEC = 16 / ESZ;
@@ -53,26 +53,34 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ZLINES = (ZW + LP - 1) / LP;
     constexpr int Z_BYTES = ZH * ZLINES * 128;
     constexpr int K_BYTES = (DB ? 2 : 1) * STAGE;
-    constexpr int SMEM = K_BYTES > Z_BYTES ? K_BYTES : Z_BYTES;
+    // PERSIST (single-chunk layers, Cin = BK): the workgroup walks several tiles; the weights stay in LDS, the next
+    // tile's patch is fetched during the blur of the current one, so the z tile gets its own region
+    constexpr int Z_OFF = PERSIST ? STAGE : 0;
+    constexpr int SMEM = PERSIST ? STAGE + Z_BYTES : (K_BYTES > Z_BYTES ? K_BYTES : Z_BYTES);
     static_assert(QY % NW == 0 && CN % 16 == 0 && 128 % PXB == 0 && CN % 8 == 0, "tile shape");
+    static_assert(!(PERSIST && DB), "persistent form is single-chunk");
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert(PA + LBC < 64, "vmcnt is 6 bits");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
     auto sA = [&](int b) -> unsigned char* { return smem + b * STAGE; };
     auto sB = [&](int b) -> unsigned char* { return smem + b * STAGE + A_BYTES; };
+    unsigned char* const zbase = smem + Z_OFF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = vt_uniform(tid >> 6) & (NW - 1);
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
-    int tile_m, tile_n, split;
-    decode_block(p, tile_m, tile_n, split);
+    int tile_m, tile_n, split, tile_step;
+    if (PERSIST) {
+        tile_n = (int)(blockIdx.x % (unsigned)p.tiles_n);
+        tile_m = (int)(blockIdx.x / (unsigned)p.tiles_n);
+        tile_step = (int)(gridDim.x / (unsigned)p.tiles_n);
+    } else {
+        decode_block(p, tile_m, tile_n, split);
+        tile_step = 0x40000000;
+    }
     const int per_img = g.tiles_y * g.tiles_x;
-    const int img = tile_m / per_img;
-    const int trem = tile_m - img * per_img;
-    const int u0 = (trem / g.tiles_x) * TY, v0 = (trem % g.tiles_x) * TX;   // first output pixel of the tile
-    const int I0 = u0 / 2, J0 = v0 / 2;
     const int n0 = tile_n * CN;
     const int OH = 2 * p.H, OW = 2 * p.W;
 
@@ -80,15 +88,19 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     const int lrow = lane >> 3;
     const int jj = l7 ^ lrow;
     uint32_t pa0[PA];
+    auto set_patch = [&](int tm) {
+        const int im = tm / per_img, tr = tm - im * per_img;
+        const int I0 = ((tr / g.tiles_x) * TY) / 2, J0 = ((tr % g.tiles_x) * TX) / 2;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int pr = (i * NW + wave) * 8 + lrow;
-        const int py = pr / PW, px = pr - py * PW;
-        const int iy = I0 - 2 + py, ix = J0 - 2 + px;
-        const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
-        pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
-    }
+        for (int i = 0; i < PA; ++i) {
+            const int pr = (i * NW + wave) * 8 + lrow;
+            const int py = pr / PW, px = pr - py * PW;
+            const int iy = I0 - 2 + py, ix = J0 - 2 + px;
+            const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t pix = (uint32_t)((im * p.H + iy) * p.W + ix);
+            pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
+        }
+    };
     // weights of a chunk: LDS row t*CN + r = tap t, tile row r (fragment order, see tile_row_channel)
     uint32_t woff[LBC];
 #pragma unroll
@@ -106,118 +118,18 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     // one chunk = BK input channels: its patch AND all 9 taps of its weights are LDS-resident, so the 9 taps run
     // without a barrier (a 3-stage per-tap weight ring measured ~1 us per tap step: two taps in flight do not
     // cover the L2 latency).  DB: the next chunk loads into the other stage while this one computes (one
-    // workgroup per CU, the deep layers); !DB: single stage, two workgroups per CU cover each other's loads
-    // and blur phases (the 64/128-channel levels).
-    auto issue = [&](int chunk, int st) {
+    // workgroup per CU, the deep layers); !DB: single stage, two workgroups per CU.
+    auto issue = [&](int chunk, int st, bool with_weights) {
         const uint32_t so = (uint32_t)(chunk * BK * ESZ);
 #pragma unroll
         for (int i = 0; i < PA; ++i) vt_glds16(r0, sA(st) + (i * NW + wave) * 1024, pa0[i], so);
+        if (with_weights) {
 #pragma unroll
-        for (int i = 0; i < LBC; ++i) vt_glds16(rw, sB(st) + (i * NW + wave) * 1024, woff[i], so);
+            for (int i = 0; i < LBC; ++i) vt_glds16(rw, sB(st) + (i * NW + wave) * 1024, woff[i], so);
+        }
     };
 
-    f32x4 acc[4][MF][TN];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < MF; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    issue(0, 0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int st = DB ? (chunk & 1) : 0;
-        if (DB) {
-            // stage st^1 was read by chunk - 1: every wave is past it once it has reached this barrier
-            vt_glds_wait_n<0>();
-            vt_lds_barrier();
-            if (chunk + 1 < nchunks) issue(chunk + 1, st ^ 1);
-        } else {
-            vt_glds_wait_n<0>();
-            vt_lds_barrier();
-        }
-        const unsigned char* pa = sA(st);
-        const unsigned char* pb = sB(st);
-        if (p.dbg == 12) continue;   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): loads only
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int slot = sub * 4 + q;
-            // taps grouped by input shift (a/2, b/2): the four taps (0|1, 0|1) share one set of pixel fragments
-#pragma unroll
-            for (int sh = 0; sh < 4; ++sh) {
-                const int di = sh >> 1, dj = sh & 1;
-                u128 fa[MF];
-#pragma unroll
-                for (int m = 0; m < MF; ++m) {
-                    const int pr = (wave * MF + m + 1 - di) * PW + (1 - dj) + l15;
-                    fa[m] = ld128(pa + pr * 128 + ((slot ^ (pr & 7)) << 4));
-                }
-#pragma unroll
-                for (int ta = 2 * di; ta < (di ? 3 : 2); ++ta)
-#pragma unroll
-                    for (int tb = 2 * dj; tb < (dj ? 3 : 2); ++tb) {
-                        const int tap = ta * 3 + tb, cls = (ta & 1) * 2 + (tb & 1);
-                        u128 fb[TN];
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-                            fb[n] = ld128(pb + (tap * CN + n * 16 + l15) * 128 + ((slot ^ l7) << 4));
-#pragma unroll
-                        for (int m = 0; m < MF; ++m)
-#pragma unroll
-                            for (int n = 0; n < TN; ++n) Mma<T>::run(acc[cls][m][n], fb[n], fa[m]);
-                    }
-            }
-        }
-        if (!DB && chunk + 1 < nchunks) {
-            vt_lds_barrier();   // every wave is done reading the stage
-            issue(chunk + 1, 0);
-        }
-    }
-    __syncthreads();   // patch / ring buffers are dead: the z tile goes over them
-    if (p.dbg == 11 || p.dbg == 12) {   // ablation: no z tile, no blur, no store
-        float sacc = 0.f;
-        for (int c = 0; c < 4; ++c)
-            for (int m = 0; m < MF; ++m)
-                for (int n = 0; n < TN; ++n) sacc += acc[c][m][n][0] + acc[c][m][n][1] + acc[c][m][n][2] + acc[c][m][n][3];
-        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
-        return;
-    }
-
-    // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile -----
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int zpa = c >> 1, zpb = c & 1;
-#pragma unroll
-        for (int m = 0; m < MF; ++m) {
-            const int zy = 2 * (wave * MF + m) + zpa - 1, zx = 2 * l15 + zpb - 1;
-            if (zy < 0 || zx < 0) continue;
-            const int line = zx / LP, subp = zx - line * LP;
-            unsigned char* zl = smem + (zy * ZLINES + line) * 128;
-#pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const int ch = frag_channel<PERM>(n, q);                // first of this lane's 4 channels
-                const int b0 = subp * PXB + ch * ESZ;                   // byte offset inside the line
-                const int phys = ((b0 >> 4) ^ (line & 7)) << 4;
-                float f[4] = {acc[c][m][n][0], acc[c][m][n][1], acc[c][m][n][2], acc[c][m][n][3]};
-                if (ESZ == 2) {
-                    u64v v;
-                    v.x = pack_bf16x2(f[0], f[1]);
-                    v.y = pack_bf16x2(f[2], f[3]);
-                    *reinterpret_cast<u64v*>(zl + phys + (b0 & 15)) = v;
-                } else {
-                    st128(zl + phys, pack16<float>(f));
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    if (p.dbg == 14) return;   // ablation: stop after the z tile
-    // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
-    // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
-    // This phase is pure vector-ALU work (measured 70 % of the kernel before it was trimmed): explicit fmaf
-    // (the build runs -ffp-contract=off), branch-free rows, addresses as one register per tap + immediates,
-    // bias folded into the vertical sum, activation as one select.
+    // ---- blur constants (phase 3), fixed for the workgroup ----------------------------------------------------
     constexpr int NV = CN / VEC;                 // 16-byte channel vectors per pixel
     constexpr int GROUPS = 256 / (TX * NV) >= 1 ? 256 / (TX * NV) : 1;
     constexpr int ROWS = TY / GROUPS;
@@ -239,8 +151,6 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ky[i] *= inv;
     const int qv = tid % NV, col = (tid / NV) % TX, grp = tid / (NV * TX);
-    if (grp >= GROUPS) return;
-    const int ov = v0 + col;
     const int nch = n0 + qv * VEC;
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
     float bv[VEC], gpos[VEC], gneg[VEC];   // act(v) * gain = v * (v > 0 ? gpos : gneg)
@@ -260,69 +170,184 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         const int zx = col + t;
         const int line = zx / LP, subp = zx - line * LP;
         const int s = (subp * PXB + qv * 16) >> 4;
-        zt[t] = smem + (r0w * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
+        zt[t] = zbase + (r0w * ZLINES + line) * 128 + ((s ^ (line & 7)) << 4);
     }
-    // Row rr of the horizontally filtered tile feeds the four output rows rr-3 .. rr: four running sums per
-    // channel (ring slot = output row & 3), so no arithmetic chain is longer than three dependent operations
-    // (dependent v_pk_fma chains ran at 5-6 cycles per instruction with one or two waves per SIMD).  The row
-    // loop is a REAL loop of 4-row bodies (static ring slots inside): fully unrolled the compiler hoisted every
-    // LDS read and needed 472 registers.
-    float osum[4][VEC];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) osum[j][k] = 0.0f;
-    T* orow = (T*)p.out + (((int64_t)img * OH + u0 + r0w) * OW + ov) * p.ld_out + nch;   // output row r0w of this thread
     const int64_t ostep = (int64_t)OW * p.ld_out;
     const bool full = nch + VEC <= p.coutT;
-    const bool colok = ov < OW;
-    constexpr int NIT = (ROWS + 3 + 3) / 4;
-#pragma unroll 1
-    for (int it = 0; it < NIT; ++it) {
-        const int zoff = it * 4 * (ZLINES * 128);
+
+    if (tile_m >= p.tiles_m) return;
+    set_patch(tile_m);
+    issue(0, 0, true);
+    for (; tile_m < p.tiles_m; tile_m += tile_step) {
+        const int img = tile_m / per_img;
+        const int trem = tile_m - img * per_img;
+        const int u0 = (trem / g.tiles_x) * TY, v0 = (trem % g.tiles_x) * TX;   // first output pixel of the tile
+
+        f32x4 acc[4][MF][TN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = it * 4 + j;
-            if (rr >= ROWS + 3) break;   // uniform
-            float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
-            if (p.dbg == 16) {   // ablation: no LDS reads in the blur
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
-            } else {
-                unpack16<T>(ld128(zt[0] + zoff + j * (ZLINES * 128)), f0);
-                unpack16<T>(ld128(zt[1] + zoff + j * (ZLINES * 128)), f1);
-                unpack16<T>(ld128(zt[2] + zoff + j * (ZLINES * 128)), f2);
-                unpack16<T>(ld128(zt[3] + zoff + j * (ZLINES * 128)), f3);
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[c][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- 1. transposed conv: 9 taps per chunk, accumulator set = parity class of the tap -------------------
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int st = DB ? (chunk & 1) : 0;
+            // (DB: stage st^1 was read by chunk - 1: every wave is past it once it has reached this barrier)
+            vt_glds_wait_n<0>();
+            vt_lds_barrier();
+            if (DB && chunk + 1 < nchunks) issue(chunk + 1, st ^ 1, true);
+            const unsigned char* pa = sA(st);
+            const unsigned char* pb = sB(st);
+            if (p.dbg == 12) continue;   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): loads only
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int slot = sub * 4 + q;
+                // taps grouped by input shift (a/2, b/2): the four taps (0|1, 0|1) share one set of pixel fragments
+#pragma unroll
+                for (int sh = 0; sh < 4; ++sh) {
+                    const int di = sh >> 1, dj = sh & 1;
+                    u128 fa[MF];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) {
+                        const int pr = (wave * MF + m + 1 - di) * PW + (1 - dj) + l15;
+                        fa[m] = ld128(pa + pr * 128 + ((slot ^ (pr & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int ta = 2 * di; ta < (di ? 3 : 2); ++ta)
+#pragma unroll
+                        for (int tb = 2 * dj; tb < (dj ? 3 : 2); ++tb) {
+                            const int tap = ta * 3 + tb, cls = (ta & 1) * 2 + (tb & 1);
+                            u128 fb[TN];
+#pragma unroll
+                            for (int n = 0; n < TN; ++n)
+                                fb[n] = ld128(pb + (tap * CN + n * 16 + l15) * 128 + ((slot ^ l7) << 4));
+#pragma unroll
+                            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                                for (int n = 0; n < TN; ++n) Mma<T>::run(acc[cls][m][n], fb[n], fa[m]);
+                        }
+                }
             }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
-            // output row rr - t takes this row with vertical tap t; its sum lives in slot (j - t) & 3.  Rows
-            // outside 0..ROWS-1 only ever touch slots that are re-initialised (t == 0) before they are stored.
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                osum[(j + 3) & 3][k] = fmaf(h[k], ky[1], osum[(j + 3) & 3][k]);
-                osum[(j + 2) & 3][k] = fmaf(h[k], ky[2], osum[(j + 2) & 3][k]);
-                osum[(j + 1) & 3][k] = fmaf(h[k], ky[3], osum[(j + 1) & 3][k]);
-                osum[j][k] = fmaf(h[k], ky[0], bv[k]);
+            if (!DB && chunk + 1 < nchunks) {
+                vt_lds_barrier();   // every wave is done reading the stage
+                issue(chunk + 1, 0, true);
             }
-            const int u = rr - 3;            // finished: rows u .. u+3 have all been added to slot (j + 1) & 3
-            if (u < 0 || u >= ROWS) continue;   // uniform
-            float f[VEC];
+        }
+        __syncthreads();   // the patch (and, unless PERSIST, the whole stage) is dead
+        if (PERSIST && tile_m + tile_step < p.tiles_m) {   // next tile's patch flies during the z tile + blur
+            set_patch(tile_m + tile_step);
+            issue(0, 0, false);
+        }
+        if (p.dbg == 11 || p.dbg == 12) {   // ablation: no z tile, no blur, no store
+            float sacc = 0.f;
+            for (int c = 0; c < 4; ++c)
+                for (int m = 0; m < MF; ++m)
+                    for (int n = 0; n < TN; ++n) sacc += acc[c][m][n][0] + acc[c][m][n][1] + acc[c][m][n][2] + acc[c][m][n][3];
+            if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
+            continue;
+        }
+
+        // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile --
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const float v = osum[(j + 1) & 3][k];
-                f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
-            }
-            T* o = orow + u * ostep;
-            if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
-            if (u0 + r0w + u < OH && colok) {
-                if (full) {
-                    st128(o, pack16<T>(f));
-                } else {
-                    for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+        for (int c = 0; c < 4; ++c) {
+            const int zpa = c >> 1, zpb = c & 1;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const int zy = 2 * (wave * MF + m) + zpa - 1, zx = 2 * l15 + zpb - 1;
+                if (zy < 0 || zx < 0) continue;
+                const int line = zx / LP, subp = zx - line * LP;
+                unsigned char* zl = zbase + (zy * ZLINES + line) * 128;
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const int ch = frag_channel<PERM>(n, q);                // first of this lane's 4 channels
+                    const int b0 = subp * PXB + ch * ESZ;                   // byte offset inside the line
+                    const int phys = ((b0 >> 4) ^ (line & 7)) << 4;
+                    float f[4] = {acc[c][m][n][0], acc[c][m][n][1], acc[c][m][n][2], acc[c][m][n][3]};
+                    if (ESZ == 2) {
+                        u64v v;
+                        v.x = pack_bf16x2(f[0], f[1]);
+                        v.y = pack_bf16x2(f[2], f[3]);
+                        *reinterpret_cast<u64v*>(zl + phys + (b0 & 15)) = v;
+                    } else {
+                        st128(zl + phys, pack16<float>(f));
+                    }
                 }
             }
         }
+        __syncthreads();
+        if (p.dbg == 14) continue;   // ablation: stop after the z tile
+
+        // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
+        // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
+        // Pure vector-ALU work (70 % of the kernel before it was trimmed): explicit fmaf (the build runs
+        // -ffp-contract=off), addresses as one register per tap + immediates, bias folded into the vertical sum,
+        // activation as one select.  Row rr of the horizontally filtered tile feeds the four output rows
+        // rr-3 .. rr: four running sums per channel (ring slot = output row & 3), so no arithmetic chain is longer
+        // than three dependent operations (dependent v_pk_fma chains ran at 5-6 cycles per instruction).  The row
+        // loop is a REAL loop of 4-row bodies (static ring slots inside): fully unrolled the compiler hoisted
+        // every LDS read and needed 472 registers.
+        if (grp < GROUPS) {
+            const int ov = v0 + col;
+            float osum[4][VEC];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) osum[j][k] = 0.0f;
+            T* orow = (T*)p.out + (((int64_t)img * OH + u0 + r0w) * OW + ov) * p.ld_out + nch;   // this thread's row r0w
+            const bool colok = ov < OW;
+            constexpr int NIT = (ROWS + 3 + 3) / 4;
+#pragma unroll 1
+            for (int it = 0; it < NIT; ++it) {
+                const int zoff = it * 4 * (ZLINES * 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = it * 4 + j;
+                    if (rr >= ROWS + 3) break;   // uniform
+                    float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
+                    if (p.dbg == 16) {   // ablation: no LDS reads in the blur
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
+                    } else {
+                        unpack16<T>(ld128(zt[0] + zoff + j * (ZLINES * 128)), f0);
+                        unpack16<T>(ld128(zt[1] + zoff + j * (ZLINES * 128)), f1);
+                        unpack16<T>(ld128(zt[2] + zoff + j * (ZLINES * 128)), f2);
+                        unpack16<T>(ld128(zt[3] + zoff + j * (ZLINES * 128)), f3);
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
+                    // output row rr - t takes this row with vertical tap t; its sum lives in slot (j - t) & 3.  Rows
+                    // outside 0..ROWS-1 only touch slots that are re-initialised (t == 0) before they are stored.
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        osum[(j + 3) & 3][k] = fmaf(h[k], ky[1], osum[(j + 3) & 3][k]);
+                        osum[(j + 2) & 3][k] = fmaf(h[k], ky[2], osum[(j + 2) & 3][k]);
+                        osum[(j + 1) & 3][k] = fmaf(h[k], ky[3], osum[(j + 1) & 3][k]);
+                        osum[j][k] = fmaf(h[k], ky[0], bv[k]);
+                    }
+                    const int u = rr - 3;            // finished: rows u .. u+3 have all been added to slot (j + 1) & 3
+                    if (u < 0 || u >= ROWS) continue;   // uniform
+                    float f[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float v = osum[(j + 1) & 3][k];
+                        f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
+                    }
+                    T* o = orow + u * ostep;
+                    if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
+                    if (u0 + r0w + u < OH && colok) {
+                        if (full) {
+                            st128(o, pack16<T>(f));
+                        } else {
+                            for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
+                        }
+                    }
+                }
+            }
+        }
+        // (PERSIST: the wait + barrier at the top of the next tile's chunk loop also fences the z tile)
     }
 }
 
@@ -345,7 +370,7 @@ static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
     return true;
 }
 
-template <typename T, int CN, int QY, int DB>
+template <typename T, int CN, int QY, int DB, int PERSIST>
 int launch_upblur(const ConvArgs& a, vt_stream stream) {
     UpblurArgs g;
     if (!upblur_eligible<T>(a, g, 2 * (QY - 2), 28)) {
@@ -358,12 +383,20 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
     args.slab_perm = 0;
     args.tiles_n = vt_cdiv(a.coutT, CN);
     args.tiles_m = a.N * g.tiles_y * g.tiles_x;
-    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n;
+    int64_t blocks = (int64_t)args.tiles_m * args.tiles_n;
     if (blocks >= ((int64_t)1 << 31)) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    auto k = conv_upblur_kernel<T, CN, QY, DB>;
+    if (PERSIST) {   // one workgroup per CU (256 CUs), each walks tiles_m / (grid / tiles_n) tiles of one channel tile
+        const char* e = getenv("VT_UPBLUR_WGS");   // tests: few workgroups = several tiles each
+        const int pwg = e && atoi(e) > 0 ? atoi(e) : 256;
+        int per_n = pwg / args.tiles_n;
+        if (per_n < 1) per_n = 1;
+        if (per_n > args.tiles_m) per_n = args.tiles_m;
+        blocks = (int64_t)per_n * args.tiles_n;
+    }
+    auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
     return vt_check_launch("vt_conv2d(upblur)");
 }
