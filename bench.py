@@ -73,7 +73,12 @@ def pmc_traffic(kernel_class: str):
     else:
         name, dt, bm, bn = m.group(1), m.group(2), int(m.group(3)), int(m.group(4))
         tt = "bf16_t" if dt == "bf16" else "float"
-        lead = f"{name}<{tt}, {bm // 16 if name == 'conv_patch_kernel' else bm}, {bn},"
+        if name == "conv_fullk_kernel":
+            lead = f"{name}<{tt}>"
+        elif name == "conv_upblur_kernel":
+            lead = f"{name}<{tt}, {bn},"
+        else:
+            lead = f"{name}<{tt}, {bm // 16 if name == 'conv_patch_kernel' else bm}, {bn},"
         hit = [v for k, v in table.items() if k.startswith(lead)]
     n = sum(v["launches_sampled"] for v in hit)
     if not n:
