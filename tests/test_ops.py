@@ -786,7 +786,7 @@ def test_conv_transpose_blur_kernel(dev, dtype):
     k1 = np.array([1, 3, 3, 1], np.float32)
     fir = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)       # make_kernel([1,3,3,1]) * factor^2 (model.py:66,192-198)
     for N, cin, H, W, cout, hint in [(1, unit, 5, 7, 32, 32), (2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 16),
-                                     (1, 3 * unit, 6, 15, 64, 0), (1, 5 * unit, 6, 9, 32, 32)]:   # >= 4 chunks: double-buffered
+                                     (1, 3 * unit, 6, 15, 64, 0), (1, 5 * unit, 6, 9, 32, 16)]:   # 16-channel tiles, >= 4 chunks: double-buffered
         x = g.standard_normal((N, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
         b = g.standard_normal(cout).astype(np.float32)

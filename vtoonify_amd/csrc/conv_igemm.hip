@@ -1856,16 +1856,24 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         // deep layers (>= 4 channel chunks): double-buffered chunks, one workgroup per CU; shallow ones: single
         // stage, two workgroups per CU
         const int chunks = a.cin / (8 * (16 / (int)sizeof(T)));
-        const bool db = chunks >= 4;
+        // double-buffered chunks (one workgroup per CU) only pay on the 16-channel tiles of the deepest layer
+        // (33 vs 37 us); the 32-channel tiles run single-stage with two workgroups per CU (44 vs 51 us at 512->256)
+        const char* de = getenv("VT_UPBLUR_DB");    // A/B: minimum chunk count of the double-buffered form
+        const bool db = de ? chunks >= atoi(de) : (t.bn == 16 && chunks >= 4);
         // single-chunk layers with many tiles per CU (the 1024^2 level): persistent workgroups, resident weights.
         // VT_UPBLUR_PERSIST = minimum number of workgroups for the persistent form (0 = never; tests use 1)
         const char* pe = getenv("VT_UPBLUR_PERSIST");
-        const int64_t persist_min = pe ? atoll(pe) : 512;
+        const int64_t persist_min = pe ? atoll(pe) : 0;   // measured slower than two plain workgroups per CU (54 vs 70 us)
         const int64_t tiles = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28);
+        // single-stage forms capped at 256 registers (2 workgroups per CU, a few cold values spilled): 40 vs 51 us
+        // and 54 vs 77 us on the 256^2 / 512^2-pixel levels; VT_UPBLUR_LB2=0 for the uncapped build
+        const char* le = getenv("VT_UPBLUR_LB2");
+        const bool lb2 = !(le && le[0] == '0');
         if (t.bn == 32 && chunks == 1 && persist_min > 0 && tiles * vt_cdiv(a.coutT, 32) >= persist_min)
-            return launch_upblur<T, 32, 12, 0, 1>(a, stream);
-        if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1, 0>(a, stream) : launch_upblur<T, 16, 12, 0, 0>(a, stream);
-        return db ? launch_upblur<T, 32, 12, 1, 0>(a, stream) : launch_upblur<T, 32, 12, 0, 0>(a, stream);
+            return launch_upblur<T, 32, 12, 0, 1, 0>(a, stream);
+        if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1, 0, 0>(a, stream) : launch_upblur<T, 16, 12, 0, 0, 0>(a, stream);
+        if (db) return launch_upblur<T, 32, 12, 1, 0, 0>(a, stream);
+        return lb2 ? launch_upblur<T, 32, 12, 0, 0, 1>(a, stream) : launch_upblur<T, 32, 12, 0, 0, 0>(a, stream);
     }
     if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);

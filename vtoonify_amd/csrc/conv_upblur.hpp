@@ -30,8 +30,8 @@ struct UpblurArgs {
     int tiles_y, tiles_x;     // output tiles per image
 };
 
-template <typename T, int CN, int QY, int DB, int PERSIST>
-__global__ void __launch_bounds__(256, PERSIST ? 1 : 2)   // !PERSIST: two 4-wave workgroups per CU (<= 256 registers)
+template <typename T, int CN, int QY, int DB, int PERSIST, int LB2>
+__global__ void __launch_bounds__(256, LB2 ? 2 : 1)   // LB2: cap at 256 registers so that two 4-wave workgroups share a CU
 conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VEC = 16 / ESZ;
@@ -134,34 +134,39 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int GROUPS = 256 / (TX * NV) >= 1 ? 256 / (TX * NV) : 1;
     constexpr int ROWS = TY / GROUPS;
     static_assert(TX * NV <= 256 && TY % GROUPS == 0, "one thread per (column, channel vector, row group)");
-    const float* fir = p.up_fir;
-    float kx[4], ky[4], ksum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kx[i] = ky[i] = 0.0f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const float t = fir[(3 - a) * 4 + (3 - b)];   // upfirdn2d applies the flipped kernel
-            ky[a] += t;
-            kx[b] += t;
-            ksum += t;
-        }
-    const float inv = 1.0f / ksum;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ky[i] *= inv;
+    float kx[4], ky[4], bv[VEC], gpos[VEC], gneg[VEC];   // act(v) * gain = v * (v > 0 ? gpos : gneg)
     const int qv = tid % NV, col = (tid / NV) % TX, grp = tid / (NV * TX);
     const int nch = n0 + qv * VEC;
-    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
-    float bv[VEC], gpos[VEC], gneg[VEC];   // act(v) * gain = v * (v > 0 ? gpos : gneg)
+    // (computed AFTER the accumulation loop unless the workgroup is persistent: ~50 registers that would
+    // otherwise be live across the MFMA loop and push the two-workgroups-per-CU form over its 256-register cap)
+    auto blur_consts = [&]() {
+        const float* fir = p.up_fir;
+        float ksum = 0.0f;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const int nn = nch + k;
-        bv[k] = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
-        const float sl = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
-        gpos[k] = ga;
-        gneg[k] = (p.act == VT_ACT_LRELU) ? ga * sl : ga;
-    }
+        for (int i = 0; i < 4; ++i) kx[i] = ky[i] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float t = fir[(3 - a) * 4 + (3 - b)];   // upfirdn2d applies the flipped kernel
+                ky[a] += t;
+                kx[b] += t;
+                ksum += t;
+            }
+        const float inv = 1.0f / ksum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ky[i] *= inv;
+        const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int nn = nch + k;
+            bv[k] = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
+            const float sl = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
+            gpos[k] = ga;
+            gneg[k] = (p.act == VT_ACT_LRELU) ? ga * sl : ga;
+        }
+    };
+    if (PERSIST) blur_consts();
     const int r0w = grp * ROWS;
     // byte address of z pixel (row r0w, column col + t), channel vector qv: one register per tap, rows by immediates
     const unsigned char* zt[4];
@@ -178,7 +183,9 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     if (tile_m >= p.tiles_m) return;
     set_patch(tile_m);
     issue(0, 0, true);
-    for (; tile_m < p.tiles_m; tile_m += tile_step) {
+    // (not a `for` over tiles: with !PERSIST the body runs exactly once and the compiler must SEE that -- as a loop
+    // it hoisted every loop-invariant LDS address out of it and needed 480 registers)
+    for (;;) {
         const int img = tile_m / per_img;
         const int trem = tile_m - img * per_img;
         const int u0 = (trem / g.tiles_x) * TY, v0 = (trem % g.tiles_x) * TX;   // first output pixel of the tile
@@ -208,6 +215,8 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 #pragma unroll
                 for (int sh = 0; sh < 4; ++sh) {
                     const int di = sh >> 1, dj = sh & 1;
+                    vt_sched_fence();   // one shift group's fragments live at a time (the scheduler otherwise hoists
+                                        // every LDS read of the chunk: > 256 registers, spills)
                     u128 fa[MF];
 #pragma unroll
                     for (int m = 0; m < MF; ++m) {
@@ -246,7 +255,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                 for (int m = 0; m < MF; ++m)
                     for (int n = 0; n < TN; ++n) sacc += acc[c][m][n][0] + acc[c][m][n][1] + acc[c][m][n][2] + acc[c][m][n][3];
             if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
-            continue;
+            goto next_tile;
         }
 
         // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile --
@@ -277,7 +286,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             }
         }
         __syncthreads();
-        if (p.dbg == 14) continue;   // ablation: stop after the z tile
+        if (p.dbg == 14) goto next_tile;   // ablation: stop after the z tile
 
         // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
         // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
@@ -288,66 +297,57 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         // than three dependent operations (dependent v_pk_fma chains ran at 5-6 cycles per instruction).  The row
         // loop is a REAL loop of 4-row bodies (static ring slots inside): fully unrolled the compiler hoisted
         // every LDS read and needed 472 registers.
+        if (!PERSIST) blur_consts();
         if (grp < GROUPS) {
             const int ov = v0 + col;
-            float osum[4][VEC];
+            // running sums by age: o1 / o2 / o3 have received 1 / 2 / 3 vertical taps; the row that completes o3
+            // finishes output row rr - 3.  One row per iteration of a REAL loop (rotating the sums costs 24 moves
+            // per row; unrolled bodies kept 4 rows of unpacked pixels live and spilled).
+            float o1[VEC], o2[VEC], o3[VEC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) osum[j][k] = 0.0f;
-            T* orow = (T*)p.out + (((int64_t)img * OH + u0 + r0w) * OW + ov) * p.ld_out + nch;   // this thread's row r0w
+            for (int k = 0; k < VEC; ++k) o1[k] = o2[k] = o3[k] = 0.0f;
+            T* o = (T*)p.out + (((int64_t)img * OH + u0 + r0w - 3) * OW + ov) * p.ld_out + nch;   // row (rr - 3) of this thread
             const bool colok = ov < OW;
-            constexpr int NIT = (ROWS + 3 + 3) / 4;
+            const unsigned char *z0 = zt[0], *z1 = zt[1], *z2 = zt[2], *z3 = zt[3];
 #pragma unroll 1
-            for (int it = 0; it < NIT; ++it) {
-                const int zoff = it * 4 * (ZLINES * 128);
+            for (int rr = 0; rr < ROWS + 3; ++rr) {
+                float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
+                if (p.dbg == 16) {   // ablation: no LDS reads in the blur
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rr = it * 4 + j;
-                    if (rr >= ROWS + 3) break;   // uniform
-                    float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
-                    if (p.dbg == 16) {   // ablation: no LDS reads in the blur
+                    for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
+                } else {
+                    unpack16<T>(ld128(z0), f0);
+                    unpack16<T>(ld128(z1), f1);
+                    unpack16<T>(ld128(z2), f2);
+                    unpack16<T>(ld128(z3), f3);
+                }
+                z0 += ZLINES * 128; z1 += ZLINES * 128; z2 += ZLINES * 128; z3 += ZLINES * 128;
+                float f[VEC];
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
+                for (int k = 0; k < VEC; ++k) {
+                    h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
+                    const float v = fmaf(h[k], ky[3], o3[k]);     // completes output row rr - 3
+                    f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
+                    o3[k] = fmaf(h[k], ky[2], o2[k]);
+                    o2[k] = fmaf(h[k], ky[1], o1[k]);
+                    o1[k] = fmaf(h[k], ky[0], bv[k]);
+                }
+                const int u = rr - 3;
+                if (u >= 0 && u0 + r0w + u < OH && colok && !(p.dbg == 13 && f[0] != 123.456f)) {
+                    if (full) {
+                        st128(o, pack16<T>(f));
                     } else {
-                        unpack16<T>(ld128(zt[0] + zoff + j * (ZLINES * 128)), f0);
-                        unpack16<T>(ld128(zt[1] + zoff + j * (ZLINES * 128)), f1);
-                        unpack16<T>(ld128(zt[2] + zoff + j * (ZLINES * 128)), f2);
-                        unpack16<T>(ld128(zt[3] + zoff + j * (ZLINES * 128)), f3);
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
-                    // output row rr - t takes this row with vertical tap t; its sum lives in slot (j - t) & 3.  Rows
-                    // outside 0..ROWS-1 only touch slots that are re-initialised (t == 0) before they are stored.
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        osum[(j + 3) & 3][k] = fmaf(h[k], ky[1], osum[(j + 3) & 3][k]);
-                        osum[(j + 2) & 3][k] = fmaf(h[k], ky[2], osum[(j + 2) & 3][k]);
-                        osum[(j + 1) & 3][k] = fmaf(h[k], ky[3], osum[(j + 1) & 3][k]);
-                        osum[j][k] = fmaf(h[k], ky[0], bv[k]);
-                    }
-                    const int u = rr - 3;            // finished: rows u .. u+3 have all been added to slot (j + 1) & 3
-                    if (u < 0 || u >= ROWS) continue;   // uniform
-                    float f[VEC];
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float v = osum[(j + 1) & 3][k];
-                        f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
-                    }
-                    T* o = orow + u * ostep;
-                    if (p.dbg == 13 && f[0] != 123.456f) continue;   // ablation: everything but the global stores
-                    if (u0 + r0w + u < OH && colok) {
-                        if (full) {
-                            st128(o, pack16<T>(f));
-                        } else {
-                            for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
-                        }
+                        for (int k = 0; k < VEC && nch + k < p.coutT; ++k) o[k] = from_f32<T>(f[k]);
                     }
                 }
+                o += ostep;
             }
         }
         // (PERSIST: the wait + barrier at the top of the next tile's chunk loop also fences the z tile)
+    next_tile:
+        if (!PERSIST) break;
+        tile_m += tile_step;
+        if (tile_m >= p.tiles_m) break;
     }
 }
 
@@ -370,7 +370,7 @@ static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
     return true;
 }
 
-template <typename T, int CN, int QY, int DB, int PERSIST>
+template <typename T, int CN, int QY, int DB, int PERSIST, int LB2>
 int launch_upblur(const ConvArgs& a, vt_stream stream) {
     UpblurArgs g;
     if (!upblur_eligible<T>(a, g, 2 * (QY - 2), 28)) {
@@ -396,7 +396,7 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
         if (per_n > args.tiles_m) per_n = args.tiles_m;
         blocks = (int64_t)per_n * args.tiles_n;
     }
-    auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST>;
+    auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST, LB2>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
     return vt_check_launch("vt_conv2d(upblur)");
 }
