@@ -396,9 +396,10 @@ def main():
             roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         roofline["traffic"] = pmc_traffic(dom["kernel"])
-        # durations: hipEvent pairs around every launch minus the median cost of an EMPTY event pair on this box
-        # (`event_gap_us`, ~5 us: the event packets' own dispatch); raw sum kept as `kernel_sum_ms_raw`
-        roofline["timing"] = "hipEvent pair per launch minus the empty-pair gap"
+        # durations: hipEvent pairs around every launch minus HALF the median cost of an empty event pair on this
+        # box (`event_gap_us`: two event packets, one of which overlaps a kernel) -- the correction that makes
+        # these averages agree with rocprofv3's of the same launches; raw sum kept as `kernel_sum_ms_raw`
+        roofline["timing"] = "hipEvent pair per launch minus half the empty-pair gap"
         roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
         roofline["kernel_sum_ms_raw"] = sum(getattr(eng, "last_raw_ms", []))
         roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],

@@ -4,11 +4,14 @@
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv ...
     python tools/pmc_mfma.py <..._counter_collection.csv> > profiles/rNN_pmc_mfma.json
 
-SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's MFMA pipe is busy, summed over the SIMDs the
-counter instance covers (MI355X_MICROARCH.md: "= 32 x N_mfma for 32x32x16 bf16"; a 16x16x32 bf16 MFMA
-is 16 cycles).  With GRBM_GUI_ACTIVE = cycles the kernel kept the GPU busy and 1024 SIMDs on the chip
-(256 CUs x 4), utilisation = MFMA_BUSY / (GUI_ACTIVE x 1024).  The raw sums are kept next to the
-derived fraction so that a different normalisation can be applied if the counter's scope differs.
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's MFMA pipe is busy, summed over all 1024 SIMDs
+(MI355X_MICROARCH.md: "= 32 x N_mfma for 32x32x16 bf16"; checked here: = 16 x SQ_INSTS_MFMA for the
+16x16x32 bf16 kernels).  GRBM_GUI_ACTIVE is reported SUMMED OVER THE 8 XCDs (one GRBM instance each):
+GUI_ACTIVE / 8 / kernel duration = 2.0-2.1 GHz on every kernel of the r02 pass, whereas the raw value would
+mean a 17 GHz clock.  So
+    mfma_utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024 SIMDs)
+= the fraction of the chip's MFMA issue slots the kernel used while it ran (the profiled run: kernels are
+~15 % slower under rocprofv3 than un-profiled).  The raw sums are kept next to the derived fraction.
 """
 import collections
 import csv
@@ -36,9 +39,9 @@ def main(path):
         row = {"launches_sampled": n, **{c.lower() + "_per_launch": m for c, m in mean.items()}}
         busy, gui = mean.get("SQ_VALU_MFMA_BUSY_CYCLES"), mean.get("GRBM_GUI_ACTIVE")
         if busy is not None and gui:
-            row["mfma_utilisation"] = busy / (gui * SIMDS)
+            row["mfma_utilisation"] = busy / (gui / 8.0 * SIMDS)
         out[k] = row
-    json.dump({"note": "mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), mean per launch",
+    json.dump({"note": "mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), mean per launch",
                "kernels": out}, sys.stdout, indent=1)
 
 

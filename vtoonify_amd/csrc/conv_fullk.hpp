@@ -43,7 +43,7 @@ constexpr int FK_TH = 8, FK_TW = 8, FK_BN = 32, FK_NW = 8;
 constexpr int FK_PW = FK_TW + 2, FK_PH = FK_TH + 2, FK_PROWS = FK_PW * FK_PH;   // 10 x 10 patch
 constexpr int FK_PA = (FK_PROWS + 7) / 8;                                      // 13 loads of 8 rows
 constexpr int FK_ABYTES = FK_PA * 1024;                                        // 13 KB per wave
-constexpr int FK_DEPTH = 6;                                                    // weight sub-steps in flight (static_assert AHEAD ladder below)
+constexpr int FK_DEPTH_DEFAULT = 6;                                            // weight sub-steps in flight
 
 __device__ __forceinline__ int fk_swz(int px) { return ((px >> 1) & 3) << 1; }
 constexpr float FK_IN_EPS = 1e-5f;   // nn.InstanceNorm2d default (model/dualstylegan.py:10)
@@ -61,7 +61,16 @@ __device__ __forceinline__ int fk_tile_count(int t, int d, int tiles_y, int tile
     return ny * nx;
 }
 
-template <typename T>
+// vt_vmcnt_fence<2 * n>() for a value n that is a compile-time constant after unrolling (0 <= n <= MAXN)
+template <int MAXN>
+__device__ __forceinline__ void fk_wait_pairs(int n) {
+    if (n >= MAXN) vt_vmcnt_fence<2 * MAXN>();
+    else fk_wait_pairs<MAXN - 1>(n);
+}
+template <>
+__device__ __forceinline__ void fk_wait_pairs<0>(int) { vt_vmcnt_fence<0>(); }
+
+template <typename T, int FK_DEPTH>
 __global__ void __launch_bounds__(FK_NW * 64)
 conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     constexpr int ESZ = (int)sizeof(T);
@@ -235,24 +244,28 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         for (int st = 0; st < NSUB; ++st) {
             // loads issued after sub-step st's pair: the refills of the following min(DEPTH-1, NSUB-1-st) sub-steps
             constexpr int AHEAD = FK_DEPTH - 1;
-            if (st >= FK_DEPTH) {
-                if (NSUB - 1 - st >= AHEAD) vt_vmcnt_fence<2 * AHEAD>();
-                else if (NSUB - 1 - st == 4) vt_vmcnt_fence<8>();
-                else if (NSUB - 1 - st == 3) vt_vmcnt_fence<6>();
-                else if (NSUB - 1 - st == 2) vt_vmcnt_fence<4>();
-                else if (NSUB - 1 - st == 1) vt_vmcnt_fence<2>();
-                else vt_vmcnt_fence<0>();
-            }
+            if (st >= FK_DEPTH) fk_wait_pairs<AHEAD>(NSUB - 1 - st < AHEAD ? NSUB - 1 - st : AHEAD);
             const u128 w0 = wr[st % FK_DEPTH][0], w1 = wr[st % FK_DEPTH][1];
             if (st + FK_DEPTH < NSUB)
                 vt_gload16_pair_hidden(wr[st % FK_DEPTH][0], wr[st % FK_DEPTH][1], wcur + (st + FK_DEPTH) * 2048, wlane);
             if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
-                Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
+                if (p.dbg == 21) {   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): operands fetched, no MFMA
+                    acc[a][0][0] += vt_u2f(w0.x ^ fa[st & 1][a].x);
+                    acc[a][1][0] += vt_u2f(w1.x ^ fa[st & 1][a].x);
+                } else {
+                    Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
+                    Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
+                }
             }
         }
+    }
+    if (p.dbg == 22) {   // ablation: no cross-wave sum, no epilogue
+        float sacc = 0.f;
+        for (int a = 0; a < 4; ++a) sacc += acc[a][0][0] + acc[a][1][0] + acc[a][0][3] + acc[a][1][2];
+        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
+        return;
     }
     // ---- sum the 8 partial tiles through LDS (each wave parks its tile in its own patch region) ----
     // scratch image: row = tile pixel (128 B = 32 fp32 channels), 16-byte slot s at s ^ (pixel & 7)
@@ -436,7 +449,16 @@ int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    auto k = conv_fullk_kernel<T>;
-    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    static const int depth = [] {   // VT_FULLK_DEPTH: A/B of the weight ring depth (6 or 9 sub-steps)
+        const char* e = getenv("VT_FULLK_DEPTH");
+        return e ? atoi(e) : FK_DEPTH_DEFAULT;
+    }();
+    if (depth == 9) {
+        auto k = conv_fullk_kernel<T, 9>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    } else {
+        auto k = conv_fullk_kernel<T, 6>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    }
     return vt_check_launch("vt_conv2d(fullk)");
 }

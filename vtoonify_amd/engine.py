@@ -110,7 +110,11 @@ class VToonifyEngine:
         self.w: Dict[str, torch.Tensor] = {}
         for bi in range(self.n_down):
             for j in (0, 2):
-                self.w[f"encoder.{bi}.{j}"] = K.pack_conv_weight(sd[f"encoder.{bi}.{j}.weight"], out_dtype=T)
+                wsrc = sd[f"encoder.{bi}.{j}.weight"]
+                # input channels padded (zero weights) to the 128-byte K-step of the direct-to-LDS / patch kernels:
+                # the 32-channel stem output (encoder.0.0 -> encoder.0.2) otherwise drops to the register-staged loader
+                self.w[f"encoder.{bi}.{j}"] = K.pack_conv_weight(wsrc, cin_dst=self._kpad(wsrc.shape[1]) if j == 2 else None,
+                                                                 out_dtype=T)
         for ii in range(6):
             for nm in ("conv", "conv2"):
                 key = f"encoder.{self.n_down}.{ii}.{nm}"
@@ -157,6 +161,11 @@ class VToonifyEngine:
                     st = K.conv_weight_stream(wt)
                     if st is not None:
                         self._wstream[wt.data_ptr()] = st
+
+    def _kpad(self, c: int) -> int:
+        """Channel count rounded up to the K-step of the LDS loaders (64 bf16 / 32 fp32 channels = 128 bytes)."""
+        step = 64 if self.dtype == torch.bfloat16 else 32
+        return (c + step - 1) // step * step
 
     # ------------------------------------------------------------------ plan helpers
     def _buf(self, plan: _Plan, name: str, shape, dtype=None) -> torch.Tensor:
@@ -376,11 +385,16 @@ class VToonifyEngine:
                 co = wt.shape[0]
                 st = stride if j == 0 else 1
                 ho, wo = (h + 2 - 3) // st + 1, (w + 2 - 3) // st + 1
-                out = self._buf(plan, f"enc{bi}.{j}", (B, ho, wo, co))
+                # the first conv of a block writes into a K-step-padded pixel stride (pad channels stay zero, the next
+                # conv's weights for them are zero too): only the 32-channel stem output actually grows (32 -> 64)
+                cs = self._kpad(co) if j == 0 else co
+                out = self._buf(plan, f"enc{bi}.{j}", (B, ho, wo, cs))
+                if cs != co:
+                    out.zero_()
                 self._op_conv(ops, plan, src0=cur, c0=cc, ld0=cc, n=B, h=h, w=w, out_h=ho, out_w=wo,
                               weight=self.w[f"encoder.{bi}.{j}"], cout=co, kh=3, kw=3, stride=st, pad=1,
-                              bias=sd[f"encoder.{bi}.{j}.bias"], act=ACT_LRELU, slope=0.2, out=out, ld_out=co)
-                cur, cc, h, w = out, co, ho, wo
+                              bias=sd[f"encoder.{bi}.{j}.bias"], act=ACT_LRELU, slope=0.2, out=out, ld_out=cs)
+                cur, cc, h, w = out, cs, ho, wo
             feats.append((cur, cc, h, w))
         feats = feats[::-1]
         # ---- 6 x (VToonifyResBlock [+ AdaResBlock]) at H/8 (vtoonify.py:92-104, 235-239) --
@@ -801,10 +815,12 @@ class VToonifyEngine:
         stream = self._stream()
         n = len(ops)
         acc = [0.0] * n
-        # Event-to-event durations include the dispatch of the event packets themselves (~5 us per op on MI355X,
-        # measured here as the median gap of an empty event pair, self.event_gap_ms): the table reports
-        # duration - gap (what rocprofv3's begin->end kernel durations show, profiles/README.md) and keeps the
-        # raw sums in self.last_raw_ms.  An op that is two launches inside the library is one entry.
+        # Event-to-event durations include the dispatch of the event packets themselves.  An EMPTY event pair
+        # costs ~5.6 us on MI355X (self.event_gap_ms, median of 64): two packets; with a kernel between them one
+        # of the two overlaps the kernel, so the table reports duration - gap / 2 -- calibrated against
+        # rocprofv3's begin->end durations of the same launches (profiles/README.md: 16.1 vs 16.15 us for the
+        # dominant kernel).  Raw sums are kept in self.last_raw_ms.  An op that is two launches inside the library
+        # is one entry.
         cal = [torch.cuda.Event(enable_timing=True) for _ in range(65)]
         for e in cal:
             e.record()
@@ -824,7 +840,7 @@ class VToonifyEngine:
             for i in range(n):
                 acc[i] += ev[i].elapsed_time(ev[i + 1])
         self.last_raw_ms = [a / iters for a in acc]
-        return [(self._info(ops[i][2]), max(acc[i] / iters - self.event_gap_ms, 0.0)) for i in range(n)]
+        return [(self._info(ops[i][2]), max(acc[i] / iters - 0.5 * self.event_gap_ms, 0.0)) for i in range(n)]
 
     def _launch_input_only(self, plan: _Plan, stream):
         xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
