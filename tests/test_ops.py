@@ -618,7 +618,6 @@ def test_conv_whole_k_kernel(dev, dtype):
     unit = 256 if dtype == torch.float32 else 512          # 8 wavefronts x one 128-byte row of channels
     L = K.ACT_LRELU
     cases = [  # (N, c0, c1, H, W, Cout, dil, act, resid, planar)
-        (1, unit, 0, 8, 8, 32, 1, L, False, False),
         (2, unit, 0, 9, 11, 136, 1, L, True, False),            # cout >= 128: chosen without a hint
         (1, unit, 0, 9, 11, 40, 2, 0, True, False),
         (2, unit, 0, 5, 13, 64, 4, L, False, False),
@@ -690,8 +689,7 @@ def test_conv_whole_k_adain_chain(dev, dtype):
     t = 1e-4 if dtype == torch.float32 else 1.2e-2
     unit = 256 if dtype == torch.float32 else 512
     L = K.ACT_LRELU
-    for N, H, W, dA, dB, shared in [(1, 8, 8, 1, 1, True), (2, 9, 11, 1, 2, False), (1, 13, 6, 4, 1, True),
-                                    (2, 7, 10, 2, 4, True)]:
+    for N, H, W, dA, dB, shared in [(2, 9, 11, 1, 2, False), (1, 13, 6, 4, 1, True), (1, 7, 10, 2, 4, True)]:
         C = unit
         x = g.standard_normal((N, C, H, W)).astype(np.float32)
         wA = (g.standard_normal((C, C, 3, 3)) / math.sqrt(C * 9)).astype(np.float32)
@@ -785,8 +783,8 @@ def test_conv_transpose_blur_kernel(dev, dtype):
     unit = 32 if dtype == torch.float32 else 64
     k1 = np.array([1, 3, 3, 1], np.float32)
     fir = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)       # make_kernel([1,3,3,1]) * factor^2 (model.py:66,192-198)
-    for N, cin, H, W, cout, hint in [(1, unit, 5, 7, 32, 32), (2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 16),
-                                     (1, 3 * unit, 6, 15, 64, 0), (1, 5 * unit, 6, 9, 32, 16)]:   # 16-channel tiles, >= 4 chunks: double-buffered
+    for N, cin, H, W, cout, hint in [(2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 0),
+                                     (1, 5 * unit, 6, 9, 32, 16)]:   # 16-channel tiles, >= 4 chunks: double-buffered
         x = g.standard_normal((N, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
         b = g.standard_normal(cout).astype(np.float32)
