@@ -169,20 +169,34 @@ __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) 
     const vt_linear_item& L = t.it[k];
     const int o = wv - t.first_wave[k];
     const float* wr = L.W + (int64_t)o * L.in_dim;
-    const bool vec = (L.in_dim % 4 == 0) && (L.ld_x % 4 == 0) && (((uintptr_t)L.W | (uintptr_t)L.x) % 16 == 0);
+    // the summation order depends on the SHAPE only (groups of 4 consecutive inputs per lane when in_dim % 4 == 0),
+    // never on pointer alignment: an engine whose weights are views into a broadcast bucket (4-byte aligned) and
+    // one with separately allocated parameters must produce the same bits
+    const bool quad = (L.in_dim % 4 == 0);
+    const bool w16 = quad && ((uintptr_t)L.W % 16 == 0);
+    const bool x16 = quad && (L.ld_x % 4 == 0) && ((uintptr_t)L.x % 16 == 0);
     for (int r0 = 0; r0 < L.rows; r0 += RB) {
         float acc[RB];
 #pragma unroll
         for (int j = 0; j < RB; ++j) acc[j] = 0.0f;
-        if (vec) {
+        if (quad) {
             for (int i = lane * 4; i < L.in_dim; i += 256) {
                 float w4[4];
-                unpack16<float>(ld128(wr + i), w4);
+                if (w16) {
+                    unpack16<float>(ld128(wr + i), w4);
+                } else {
+                    w4[0] = wr[i]; w4[1] = wr[i + 1]; w4[2] = wr[i + 2]; w4[3] = wr[i + 3];
+                }
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
                     const int r = (r0 + j < L.rows) ? r0 + j : L.rows - 1;   // clamped: loads stay unconditional
+                    const float* xp = L.x + (int64_t)r * L.ld_x + i;
                     float x4[4];
-                    unpack16<float>(ld128(L.x + (int64_t)r * L.ld_x + i), x4);
+                    if (x16) {
+                        unpack16<float>(ld128(xp), x4);
+                    } else {
+                        x4[0] = xp[0]; x4[1] = xp[1]; x4[2] = xp[2]; x4[3] = xp[3];
+                    }
                     acc[j] += (x4[0] * w4[0] + x4[1] * w4[1]) + (x4[2] * w4[2] + x4[3] * w4[3]);
                 }
             }

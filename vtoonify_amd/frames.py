@@ -77,29 +77,33 @@ def broadcast_state_dict(shapes: Dict[str, Tuple[int, ...]], sd: Optional[Dict[s
     is known on every rank (it is the checkpoint schema); only `src` needs `sd`.
     Returns tensors on `device`, views into the received buckets."""
     keys = sorted(shapes)
+    # every tensor starts on a 256-byte boundary of its bucket: the kernels' 16-byte vector paths (weights of the
+    # style MLP, FIR taps ...) apply to the views exactly as they do to separately allocated parameters
+    ALIGN = 64
+    _padded = lambda k: (_numel(shapes[k]) + ALIGN - 1) // ALIGN * ALIGN
     ws = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     out: Dict[str, torch.Tensor] = {}
     i = 0
     while i < len(keys):
         j, n = i, 0
-        while j < len(keys) and (n == 0 or n + _numel(shapes[keys[j]]) <= bucket_elems):
-            n += _numel(shapes[keys[j]])
+        while j < len(keys) and (n == 0 or n + _padded(keys[j]) <= bucket_elems):
+            n += _padded(keys[j])
             j += 1
-        flat = torch.empty(n, dtype=torch.float32, device=device)
+        flat = torch.zeros(n, dtype=torch.float32, device=device)
         if rank == src:
             off = 0
             for k in keys[i:j]:
                 m = _numel(shapes[k])
                 flat[off:off + m].copy_(sd[k].reshape(-1).to(torch.float32))
-                off += m
+                off += _padded(k)
         if dist.is_initialized():
             dist.broadcast(flat, src=src)
         off = 0
         for k in keys[i:j]:
             m = _numel(shapes[k])
             out[k] = flat[off:off + m].view(shapes[k])
-            off += m
+            off += _padded(k)
         i = j
     return out
 
