@@ -74,7 +74,7 @@ def pmc_traffic(kernel_class: str):
         name, dt, bm, bn = m.group(1), m.group(2), int(m.group(3)), int(m.group(4))
         tt = "bf16_t" if dt == "bf16" else "float"
         if name == "conv_fullk_kernel":
-            lead = f"{name}<{tt}>"
+            lead = f"{name}<{tt}"
         elif name == "conv_upblur_kernel":
             lead = f"{name}<{tt}, {bn},"
         else:
