@@ -1126,9 +1126,11 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     const int wave = vt_uniform(tid >> 6) & 3;
     const int wm = wave;
     const int q = lane >> 4, l15 = lane & 15;
-    // 4x4 swizzle of the four 16-byte slots of a 64-byte row: conflict-free for the ds_read_b128
-    // lane groups when 16 consecutive pixels are read (slot' = slot ^ G[(pixel >> 2) & 3])
-    auto swz = [](int pr) -> int { return (0x1320 >> (((pr >> 2) & 3) * 4)) & 3; };   // G = {0,2,3,1}
+    // swizzle of the four 16-byte slots of a 64-byte row: slot' = slot ^ G[(pixel >> 2) & 3], G = {0,2,0,2}.
+    // Conflict-free for gfx950's ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) when 16 consecutive pixels are
+    // read from ANY starting pixel (tools/lds_bank_check.py; round 1's G = {0,2,3,1} was 2-way for 35 of 40
+    // starts -- it assumed contiguous 16-lane groups)
+    auto swz = [](int pr) -> int { return ((pr >> 2) & 1) << 1; };
 
     // ---- weights -> registers: fragment (tap, b): row n = b*16 + l15, k = q*8 .. q*8+7 ----------
     u128 wreg[9][TN];
