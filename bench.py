@@ -225,6 +225,11 @@ def main():
     ap.add_argument("--no-video", action="store_true", help="skip the PCIe-inclusive video-driver measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (batch4, module_call, config3); `value` is unaffected")
+    ap.add_argument("--dry-run-emu", action="store_true",
+                    help="TEST MODE (never a measurement): the host-emulation build of the kernels on CPU tensors with the "
+                         "gloo backend, so the multi-rank control flow of this file (collectives, equal block counts, "
+                         "extra keys) can run under torch.distributed.run without GPUs.  The JSON line is marked "
+                         '"data": "dry-run"')
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the --steps block until this much timed work has run; value = median block")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for cpu_baseline")
@@ -239,16 +244,30 @@ def main():
     from vtoonify_amd import _lib, frames, synth
     from vtoonify_amd.engine import VToonifyEngine
 
-    rank, local_rank, ws = frames.init()
+    emu = args.dry_run_emu
+    rank, local_rank, ws = frames.init("gloo" if emu else None)
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the package has no CPU path)")
-    _lib.use_library(_lib.DEFAULT_LIB)
-    assert not _lib.is_emulation()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    host = pin_to_gpu_numa_node(local_rank, ws)
+    if emu:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from emu import build_emu
+        _lib.use_library(build_emu.build())
+        dev = torch.device("cpu")
+        host = {"numa_node": None, "host_threads": None}
+        torch.cuda.synchronize = lambda *a, **k: None          # no device work to wait for
+        torch.cuda.current_stream = lambda *a, **k: None
+        import contextlib
+        torch.cuda.stream = lambda s: contextlib.nullcontext()
+        torch.cuda.Stream = lambda *a, **k: None
+        args.no_video, args.no_cpu_baseline, args.no_graph = True, True, True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the package has no CPU path)")
+        _lib.use_library(_lib.DEFAULT_LIB)
+        assert not _lib.is_emulation()
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        host = pin_to_gpu_numa_node(local_rank, ws)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     B, H, W = args.batch, args.height, args.width
 
@@ -300,7 +319,7 @@ def main():
             ln = i % lanes
             with torch.cuda.stream(streams[ln]):
                 return eng.forward(pl[i % 2], style, d_s, shared_style=True, use_graph=use_graph, lane=ln)
-        for i in range(lanes + 2):
+        for i in range(lanes if emu else lanes + 2):
             st(i)
             if i < lanes:
                 torch.cuda.synchronize()
@@ -313,19 +332,24 @@ def main():
     if not args.no_extras:
         # the reference's default --batch_size 4 (style_transfer.py:35) on the headline frame size, and BASELINE
         # config 3's per-rank step (4 frames of 22x144x256; 960 frames over the job = 240 / world_size steps)
-        extras["batch4"] = lanes_rate(4, H, W, 24)
-        extras["config3"] = lanes_rate(4, 144, 256, max(8, 240 // ws))
+        if emu:   # same control flow, toy sizes
+            extras["batch4"] = lanes_rate(2, H, W, 2)
+            extras["config3"] = lanes_rate(2, 16, 24, 2)
+        else:
+            extras["batch4"] = lanes_rate(4, H, W, 24)
+            extras["config3"] = lanes_rate(4, 144, 256, max(8, 240 // ws))
 
     # the same workload with ONE frame in flight (latency view; not `value`)
     single = None
     module_call = None
-    if rank == 0 and lanes > 1:
-        n1 = min(args.steps, 50)
+    reps = 1 if emu else 5
+    if rank == 0 and (lanes > 1 or emu):
+        n1 = min(args.steps, 1 if emu else 50)
         def s1(i):
             return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0)
         torch.cuda.synchronize()
         ts = []
-        for _ in range(5):
+        for _ in range(reps):
             t1 = time.perf_counter()
             for i in range(n1):
                 s1(i)
@@ -342,13 +366,15 @@ def main():
         m.load_state_dict({k: v for k, v in sd_dev.items()})
         m = m.to(dev)
         sw = style.repeat(B, 1, 1)
-        for i in range(5):
+        nwarm = 1 if emu else 5
+        for i in range(nwarm):
             ym = m(pool[i % len(pool)], sw, d_s=d_s)
         torch.cuda.synchronize()
-        assert torch.equal(ym, eng.forward(pool[4 % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0))
-        n1 = min(args.steps, 50)
+        assert torch.equal(ym, eng.forward(pool[(nwarm - 1) % len(pool)], style, d_s, shared_style=True,
+                                           use_graph=use_graph, lane=0))
+        n1 = min(args.steps, 1 if emu else 50)
         ts = []
-        for _ in range(5):
+        for _ in range(reps):
             t1 = time.perf_counter()
             for i in range(n1):
                 m(pool[i % len(pool)], sw, d_s=d_s)
@@ -364,7 +390,10 @@ def main():
         fps = ws * args.steps * B / elapsed
         # ---- per-kernel timing (HIP events on the launch stream), dominant kernel ----------
         plan = eng.plan_for(B, H, W, True, d_s != 0.0)
-        per_op = eng.time_ops(plan, iters=max(1, args.op_iters), with_style=True)
+        if emu:   # no HIP events on the host: one conv entry stands in for the table
+            per_op = [(next(info for _, info, _, _ in plan.convs), 1.0)]
+        else:
+            per_op = eng.time_ops(plan, iters=max(1, args.op_iters), with_style=True)
         classes = {}
         for info, ms in per_op:
             c = classes.setdefault(info["kernel"], {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
@@ -425,7 +454,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "timed_blocks": len(blocks), "timed_seconds": sum(blocks), "block_ms_per_step_min_max":
             [1e3 * min(blocks) / args.steps, 1e3 * max(blocks) / args.steps],
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "dry-run" if emu else "synthetic",
             "config": {"workload": f"VToonify-{'D' if args.backbone == 'dualstylegan' else 'T'} "
                                    f"22x{H}x{W} -> 3x{4 * H}x{4 * W}, batch {B} per GPU, d_s={d_s}, "
                                    f"seeded synthetic weights, style path recomputed every frame",

@@ -57,3 +57,25 @@ def test_bench_under_torch_distributed_run_one_rank():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     _check([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_two_ranks_dry_run_gloo_emulation():
+    """The N > 1 control flow of bench.py (one process per rank under torch.distributed.run, weight / style
+    broadcast, equal block counts on every rank, MAX-over-ranks timing, extra keys, rank-0-only sections, final
+    barrier) with gloo on CPU and the host-emulation kernels: `--dry-run-emu` is a TEST MODE, its numbers mean
+    nothing (the line says "data": "dry-run").  A hang or a mismatched collective here is what would lose the
+    driver's 8-GPU scaling leg."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--dry-run-emu", "--height", "8", "--width", "8", "--lanes", "1", "--min-seconds", "0",
+           "--dtype", "fp32", "--backbone", "toonify"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["data"] == "dry-run" and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "frame-parallel x2" and d["value"] > 0
+    for k in ("batch4", "config3", "single_stream", "module_call"):
+        assert d[k]["value"] > 0, k
+    assert d["cpu_baseline"] is None
