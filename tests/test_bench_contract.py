@@ -68,7 +68,7 @@ def test_bench_two_ranks_dry_run_gloo_emulation():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--dry-run-emu", "--height", "8", "--width", "8", "--lanes", "1", "--min-seconds", "0",
-           "--dtype", "fp32", "--backbone", "toonify"]
+           "--dtype", "bf16", "--backbone", "toonify"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

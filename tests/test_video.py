@@ -95,7 +95,7 @@ def _expected(eng, style, frames, parsing, dev):
 def test_video_driver_matches_frame_by_frame(dev):
     big = dev.type == "cuda"
     n, H, W = (11, 64, 96) if big else (4, 16, 24)
-    frames, parsing, eng, style = _video_case(dev, n, H, W, 2, 2, torch.bfloat16 if big else torch.float32)
+    frames, parsing, eng, style = _video_case(dev, n, H, W, 2, 2, torch.bfloat16)
     want = _expected(eng, style, frames, parsing, dev)
     for batch, depth in (((2, 2), (4, 1), (3, 3)) if big else ((3, 2),)):   # every in-flight slot builds its own plan
         got = {}
@@ -125,7 +125,7 @@ def test_video_driver_computes_parsing_maps_on_the_gpu(dev):
     from vtoonify_amd.bisenet import BiSeNetEngine
     big = dev.type == "cuda"
     n, H, W = (7, 64, 96) if big else (3, 32, 32)
-    dtype = torch.bfloat16 if big else torch.float32
+    dtype = torch.bfloat16
     frames, _, eng, style = _video_case(dev, n, H, W, 2, 2, dtype)
     bsd = synth.synth_state_dict(load_keys("bisenet"), 0)
     par = BiSeNetEngine({k: v.to(dev) for k, v in bsd.items()}, 19, dtype, dev)
