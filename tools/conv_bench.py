@@ -25,6 +25,9 @@ SHAPES = [
     ("enc2.2 512->512 @64", 64, 64, 512, 512, 3, 1, 1, 1, "nhwc"),
     ("enc3.0 512->512 s2", 64, 64, 512, 512, 3, 2, 1, 1, "nhwc"),
     ("res 512->512 @32", 32, 32, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("res 512->512 @8x32", 8, 32, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("res 512->512 @16x32", 16, 32, 512, 512, 3, 1, 1, 1, "nhwc"),
+    ("res 512->512 @32x64", 32, 64, 512, 512, 3, 1, 1, 1, "nhwc"),
     ("modres 512->512 @32 dil4", 32, 32, 512, 512, 3, 1, 4, 1, "nhwc"),
     ("fus0 1024->512 @32", 32, 32, 1024, 512, 3, 1, 1, 1, "nhwc"),
     ("mask0 1024->1 @32", 32, 32, 1024, 1, 3, 1, 1, 1, "nchw"),
@@ -77,7 +80,7 @@ def main():
     import ctypes as C
     tot = 0.0
     for name, h, w, cin, cout, k, stride, dil, phases, lay in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and (args.only[1:] != name if args.only.startswith("=") else args.only not in name):
             continue
         n = args.batch
         pad = dil * (k // 2)

@@ -70,7 +70,7 @@ __device__ __forceinline__ void fk_wait_pairs(int n) {
 template <>
 __device__ __forceinline__ void fk_wait_pairs<0>(int) { vt_vmcnt_fence<0>(); }
 
-template <typename T, int FK_DEPTH>
+template <typename T, int FK_DEPTH, int FK_AUX = 0>
 __global__ void __launch_bounds__(FK_NW * 64)
 conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     constexpr int ESZ = (int)sizeof(T);
@@ -87,6 +87,13 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     const int hi = l15 >> 3, lo = l15 & 7;
     int tile_m, tile_n, split;
     decode_block(p, tile_m, tile_n, split);
+    if (p.dbg == 23 || p.dbg == 24) {   // ablation (tools/conv_bench.py): G weight tiles per XCD-contiguous group
+        const int G = p.dbg == 23 ? 4 : p.tiles_n;   // default placement = 1 (a weight tile is shared by tiles_m WGs)
+        const int L = tile_n * p.tiles_m + tile_m;
+        const int grp = L / (p.tiles_m * G), idx = L - grp * (p.tiles_m * G);
+        tile_n = grp * G + idx % G;
+        tile_m = idx / G;
+    }
     const int d = p.dil;
     // tile_m -> (image, phase_y, phase_x, tile_y, tile_x)
     const int per_phase = g.tiles_y * g.tiles_x;
@@ -158,7 +165,7 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         const unsigned char* wcur = wround(r);
         u128 wr[FK_DEPTH][2];
 #pragma unroll
-        for (int s = 0; s < FK_DEPTH; ++s) vt_gload16_pair_hidden(wr[s][0], wr[s][1], wcur + s * 2048, wlane);
+        for (int s = 0; s < FK_DEPTH; ++s) vt_gload16_pair_hidden<FK_AUX>(wr[s][0], wr[s][1], wcur + s * 2048, wlane);
         // AdaIN prologue, part 1 (model/dualstylegan.py:16-21 ahead of every AdaResBlock conv): while the patch
         // and the first weights are in flight, merge the producer's per-tile {mean, M2} records of THIS wave's
         // channels (lane = channel) into scale / shift.  One pass, fp64, tile order (the same in every workgroup
@@ -247,7 +254,8 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
             if (st >= FK_DEPTH) fk_wait_pairs<AHEAD>(NSUB - 1 - st < AHEAD ? NSUB - 1 - st : AHEAD);
             const u128 w0 = wr[st % FK_DEPTH][0], w1 = wr[st % FK_DEPTH][1];
             if (st + FK_DEPTH < NSUB)
-                vt_gload16_pair_hidden(wr[st % FK_DEPTH][0], wr[st % FK_DEPTH][1], wcur + (st + FK_DEPTH) * 2048, wlane);
+                vt_gload16_pair_hidden<FK_AUX>(wr[st % FK_DEPTH][0], wr[st % FK_DEPTH][1], wcur + (st + FK_DEPTH) * 2048,
+                                               wlane);
             if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -453,8 +461,21 @@ int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
         const char* e = getenv("VT_FULLK_DEPTH");
         return e ? atoi(e) : FK_DEPTH_DEFAULT;
     }();
+    static const int aux = [] {     // VT_FULLK_AUX: A/B of the weight loads' cache policy (1 nt, 2 sc1, 3 sc0 sc1)
+        const char* e = getenv("VT_FULLK_AUX");
+        return e ? atoi(e) : 0;
+    }();
     if (depth == 9) {
         auto k = conv_fullk_kernel<T, 9>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    } else if (aux == 1) {
+        auto k = conv_fullk_kernel<T, 6, 1>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    } else if (aux == 2) {
+        auto k = conv_fullk_kernel<T, 6, 2>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+    } else if (aux == 3) {
+        auto k = conv_fullk_kernel<T, 6, 3>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
     } else {
         auto k = conv_fullk_kernel<T, 6>;

@@ -283,6 +283,7 @@ __device__ __forceinline__ int vt_uniform(int v) { return __builtin_amdgcn_readf
 //   base: wave-uniform pointer (SGPR pair), voff: per-lane byte offset; loads 16 B at +0 and at +1024.
 // ---------------------------------------------------------------------------------
 #ifdef VT_EMU
+template <int AUX = 0>
 static inline void vt_gload16_pair_hidden(u128& a, u128& b, const void* base, uint32_t voff) {
     a = ld128((const unsigned char*)base + voff);
     b = ld128((const unsigned char*)base + voff + 1024);
@@ -296,12 +297,27 @@ static inline void vt_vmcnt_fence() {
 }
 #else
 typedef uint32_t vt_u32x4 __attribute__((ext_vector_type(4)));
+// AUX = cache policy of the two loads (A/B knob of the whole-K conv): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+template <int AUX = 0>
 __device__ __forceinline__ void vt_gload16_pair_hidden(u128& a, u128& b, const void* base, uint32_t voff) {
     vt_u32x4 x, y;
     // s_nop 4: the base may have just come from a v_readfirstlane (VALU write of an SGPR -> VMEM read of it)
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
-                 : "=&v"(x), "=&v"(y)
-                 : "v"(voff), "s"(base));
+    if constexpr (AUX == 1)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 nt\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 nt"
+                     : "=&v"(x), "=&v"(y)
+                     : "v"(voff), "s"(base));
+    else if constexpr (AUX == 2)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc1"
+                     : "=&v"(x), "=&v"(y)
+                     : "v"(voff), "s"(base));
+    else if constexpr (AUX == 3)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc0 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024 sc0 sc1"
+                     : "=&v"(x), "=&v"(y)
+                     : "v"(voff), "s"(base));
+    else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                     : "=&v"(x), "=&v"(y)
+                     : "v"(voff), "s"(base));
     a = __builtin_bit_cast(u128, x);
     b = __builtin_bit_cast(u128, y);
 }
