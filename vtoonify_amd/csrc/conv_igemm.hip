@@ -1322,12 +1322,24 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
         float f[8];
         unpack16<float>(ld128(src), f);
         unpack16<float>(ld128(src + dc), f + 4);
-        for (int s = 1; s < p.splitk; ++s) {
-            float g[8];
-            unpack16<float>(ld128(src + s * slab), g);
-            unpack16<float>(ld128(src + s * slab + dc), g + 4);
+        // slices in order (deterministic), SG of them per memory round trip: the thin convs (masks, ToRGB,
+        // fusion_skip: 9-16 slices, a few KB of output) spent one L2 latency PER SLICE here (5-10 us a launch)
+        constexpr int SG = 8;
+        for (int s0 = 1; s0 < p.splitk; s0 += SG) {
+            float g[SG][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] += g[i];
+            for (int k = 0; k < SG; ++k) {
+                const int s = (s0 + k < p.splitk) ? s0 + k : 0;   // clamped: loads stay unconditional
+                unpack16<float>(ld128(src + s * slab), g[k]);
+                unpack16<float>(ld128(src + s * slab + dc), g[k] + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < SG; ++k) {
+                if (s0 + k < p.splitk) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] += g[k][i];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

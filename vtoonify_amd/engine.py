@@ -54,6 +54,9 @@ class _Plan:
         self.masks: List[torch.Tensor] = []
         self.graphs: dict = {}        # with_style -> torch.cuda.CUDAGraph
         self.convs: list = []         # (ConvDesc, info) of every conv launch
+        self.side = None              # side stream of the style branch (fork_style)
+        self.thin = None              # stream of the thin-op branch (fork_thin)
+        self.thin_busy = False        # thin branch forked and not yet joined (state of one _launch)
 
 
 class VToonifyEngine:
@@ -84,6 +87,10 @@ class VToonifyEngine:
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
         self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
+        # style path on a second stream / graph branch beside the encoder (VT_STYLE_FORK=0: one stream)
+        self.fork_style = os.environ.get("VT_STYLE_FORK", "1") != "0"
+        # RGB-skip path (fusion_skip conv, skip up-sampling, encoder ToRGB) on a third stream / branch
+        self.fork_thin = os.environ.get("VT_THIN_FORK", "1") != "0"
         # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
         # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
         self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
@@ -185,7 +192,7 @@ class VToonifyEngine:
             d.tile_hint = int(h)
         return d
 
-    def _op_conv(self, ops, plan, ref_macs=None, **kw):
+    def _op_conv(self, ops, plan, ref_macs=None, branch=0, join=False, **kw):
         """Append one vt_conv2d launch.  The op's info records the kernel instance (tile) and
         its ALGORITHMIC work: flops = 2 x the MACs of the reference contraction it replaces
         (`ref_macs` overrides that for the fused conv_transpose2d+blur form, whose polyphase
@@ -206,6 +213,10 @@ class VToonifyEngine:
         info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
                 "cout": cout_t, "m": m, "k": d.kh * d.kw * cin, "hw": (d.out_h, d.out_w),
                 "sig": self.conv_signature(d)}
+        if branch:
+            info["branch"] = branch
+        if join:
+            info["join"] = True
         plan.convs.append((d, info, ops, len(ops)))
         ops.append((self.lib.vt_conv2d, (C.byref(d),), info))
 
@@ -233,12 +244,38 @@ class VToonifyEngine:
             return what
         return {"name": what, "kernel": what, "flops": 0, "bytes": 0}
 
-    def _run(self, ops, stream):
+    def _run(self, ops, stream, plan=None):
+        """Issue `ops` in list order.  With a plan (and fork_thin on a GPU) the ops tagged info["branch"] = 1 --
+        the thin convs and FIR filters of the RGB skip path, which only the NEXT ToRGB needs -- go to the plan's
+        second stream: `thin.wait_stream(main)` at every main -> thin transition (a thin op may read anything
+        issued before it), `main.wait_stream(thin)` before the first main op tagged info["join"] (it reads what
+        the thin branch wrote).  Captured, that is a parallel branch of the hipGraph; the list order stays a
+        valid serial order (time_ops, emulation)."""
+        forked = plan is not None and self.fork_thin and self.device.type == "cuda"
+        cur = torch.cuda.current_stream(self.device) if forked else None
         for fn, args, what in ops:
-            rc = fn(*args, stream)
+            st = stream
+            if forked:
+                info = what if isinstance(what, dict) else {}
+                if info.get("branch"):
+                    if plan.thin is None:
+                        plan.thin = torch.cuda.Stream(self.device)
+                    if not plan.thin_busy:
+                        plan.thin.wait_stream(cur)
+                        plan.thin_busy = True
+                    st = C.c_void_p(plan.thin.cuda_stream)
+                elif plan.thin_busy and info.get("join"):
+                    cur.wait_stream(plan.thin)
+                    plan.thin_busy = False
+            rc = fn(*args, st)
             if rc != 0:
                 raise _lib.VtError(f"{self._info(what)['name']} failed (code {rc}): "
                                    f"{self.lib.vt_last_error().decode()}")
+
+    def _join_thin(self, plan):
+        if plan.thin_busy:
+            torch.cuda.current_stream(self.device).wait_stream(plan.thin)
+            plan.thin_busy = False
 
     # ------------------------------------------------------------------ style path
     def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
@@ -504,7 +541,7 @@ class VToonifyEngine:
         skip = self._buf(plan, "skip_enc", (B, 3, h, w), f32)
         self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                       weight=self.w["enc_rgb"], cout=3, kh=1, kw=1, bias=sd[f"encoder.{self.n_down + 1}.bias"],
-                      out=skip, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                      out=skip, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32, branch=1)
         plan.skip_enc = skip
 
         # ---- synthesis levels (vtoonify.py:245-272) ------------------------------------
@@ -546,7 +583,7 @@ class VToonifyEngine:
                             (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
                              C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
                              B, hw, co, dt),
-                            {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0,
+                            {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0, "join": True,
                              "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
@@ -557,7 +594,7 @@ class VToonifyEngine:
                 self._op_conv(ops, plan, src0=fem, c0=co + FEM_HDR, ld0=co + FEM_HDR, n=B, h=h, w=w, out_h=h, out_w=w,
                               weight=self.w[f"fusion_skip.{lvl}"], cout=3, kh=3, kw=3, pad=1,
                               bias=sd[f"fusion_skip.{lvl}.bias"], out=sk2, ld_out=0, out_layout=OUT_NCHW,
-                              out_dtype=K.VT_F32)
+                              out_dtype=K.VT_F32, branch=1)
                 out, skip = fo, sk2
             n1, n2, n3 = f"convs.{6 + 2 * lvl}", f"convs.{7 + 2 * lvl}", f"to_rgbs.{3 + lvl}"
             c1o = self.modw[n1].shape[0]
@@ -568,7 +605,7 @@ class VToonifyEngine:
             ops.append((lib.vt_upfirdn2d,
                         (C.c_void_p(rgb.data_ptr()), C.c_void_p(skip.data_ptr()), C.c_void_p(self.fir_rgb.data_ptr()),
                          B * 3, h, w, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, K.VT_F32),
-                        {"name": "upfirdn2d", "kernel": "upfirdn2d_tile<f32,up2>", "flops": 0,
+                        {"name": "upfirdn2d", "kernel": "upfirdn2d_tile<f32,up2>", "flops": 0, "branch": 1,
                          "bytes": B * 3 * hw * 5 * 4}))
             groups = [(0, B)] if ns == 1 else [(b, 1) for b in range(B)]
             for b0, nb in groups:
@@ -602,9 +639,9 @@ class VToonifyEngine:
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
-                self._op_conv(ops, plan, **same_kw, **(rgb_kw if fuse_rgb else {}))
+                self._op_conv(ops, plan, join=fuse_rgb, **same_kw, **(rgb_kw if fuse_rgb else {}))
                 if not fuse_rgb:
-                    self._op_conv(ops, plan, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
+                    self._op_conv(ops, plan, join=True, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
                                   h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
                                   bias=self.w[f"{n3}.bias"], beta=1.0, resid=rgb_ptr, out=rgb_ptr, ld_out=0,
                                   out_layout=OUT_NCHW, out_dtype=K.VT_F32)
@@ -616,21 +653,24 @@ class VToonifyEngine:
     def _finalize_convs(self, plan: _Plan):
         """One split-K workspace shared by every conv of the plan (launches are serial on one
         stream), then name the kernel instance each descriptor runs on."""
-        need = 0
-        for d, _, _, _ in plan.convs:
+        need = {}
+        for d, info, _, _ in plan.convs:
             b = int(self.lib.vt_conv2d_ws_bytes(C.byref(d)))
             if b < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
-            need = max(need, b)
-        ws = None
-        if need:  # zero-filled: the head of the workspace holds the split-K arrival counters
-            ws = torch.zeros((need,), dtype=torch.uint8, device=self.device)
-            plan.bufs["splitk_ws"] = ws
+            br = info.get("branch", 0)
+            need[br] = max(need.get(br, 0), b)
+        wss = {}
+        for br, nb in need.items():   # one workspace per branch (launches of a branch are serial on its stream)
+            if nb:  # zero-filled: the head of the workspace holds the split-K arrival counters
+                wss[br] = torch.zeros((nb,), dtype=torch.uint8, device=self.device)
+                plan.bufs["splitk_ws" if br == 0 else f"splitk_ws{br}"] = wss[br]
         tname = "bf16" if self.dt == K.VT_BF16 else "f32"
         inserts = []
         for d, info, ops, pos in plan.convs:
+            ws = wss.get(info.get("branch", 0))
             if ws is not None:
-                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), need
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
             tile = self.lib.vt_conv2d_tile(C.byref(d))
             if tile < 0:
                 raise _lib.VtError(f"vt_conv2d descriptor rejected: {self.lib.vt_last_error().decode()}")
@@ -651,6 +691,8 @@ class VToonifyEngine:
                 rk = "conv_splitk_reduce_stats_kernel" if d.stats_part else "conv_splitk_reduce_kernel"
                 rinfo = {"name": "splitk_reduce", "kernel": rk, "flops": 0,
                          "bytes": sk * m * ((cout_t + 7) // 8 * 8) * 4 + m * cout_t * osz}
+                if info.get("branch"):
+                    rinfo["branch"] = info["branch"]
                 inserts.append((ops, pos, (self.lib.vt_conv2d, (C.byref(d2),), rinfo)))
         # insert the reduce ops right after their slice ops (back to front keeps positions valid)
         for ops, pos, op in sorted(inserts, key=lambda t: -t[1]):
@@ -779,11 +821,27 @@ class VToonifyEngine:
         rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()), B, cin,
                                       H * W, K.VT_F32, self.dt, stream)
         _lib.check(rc, "vt_nchw_to_nhwc")
-        if with_style:
+        fork = with_style and self.fork_style and self.device.type == "cuda"
+        if fork:
+            # The style path (mapping MLPs, modulation) and the encoder share nothing until the generator: two
+            # branches -- a fork / join of streams when eager, two parallel branches of the hipGraph when
+            # captured.  The side stream first waits for everything already on this one (the previous frame's
+            # generator still reads the buffers the style path rewrites).
+            cur = torch.cuda.current_stream(self.device)
+            if plan.side is None:
+                plan.side = torch.cuda.Stream(self.device)
+            plan.side.wait_stream(cur)
+            with torch.cuda.stream(plan.side):
+                self._run(plan.style_ops, C.c_void_p(plan.side.cuda_stream))
+        elif with_style:
             self._run(plan.style_ops, stream)
-        self._run(plan.enc_ops, stream)
+        plan.thin_busy = False
+        self._run(plan.enc_ops, stream, plan)
+        if fork:
+            cur.wait_stream(plan.side)
         if with_gen:
-            self._run(plan.gen_ops, stream)
+            self._run(plan.gen_ops, stream, plan)
+        self._join_thin(plan)
 
     def _replay(self, plan: _Plan, with_style: bool):
         """hipGraph replay of the whole frame: ~140 kernel launches become one graph launch
