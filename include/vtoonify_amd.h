@@ -131,7 +131,8 @@ typedef struct vt_conv_desc {
                               (every launch leaves them zero).  Small-M /                            */
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
                               as separate workgroups and are summed in slice order (deterministic) by a
-                              second kernel (or by the last slice to arrive, VT_SPLITK_IN_LAUNCH=1); vt_conv2d_ws_bytes() says how much the heuristic wants */
+                              second kernel, or -- thin outputs, cout <= 8 -- by the last slice to arrive
+                              (vt_conv2d_splitk_mode()); vt_conv2d_ws_bytes() says how much the heuristic wants */
     const float* slope_vec; /* optional per-output-channel negative slope [cout] for VT_ACT_LRELU
                               (nn.PReLU of the pSp encoder, model/encoder/encoders/helpers.py:97-119);
                               NULL = the scalar `slope` */
@@ -192,6 +193,10 @@ int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
 int vt_conv2d_tile(const vt_conv_desc* desc);
 /* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */
 int64_t vt_conv2d_ws_bytes(const vt_conv_desc* desc);
+/* How vt_conv2d would finish a split-K launch of `desc`: 0 = it does not split, 1 = in the same launch (the last
+ * slice to arrive at a tile's ticket sums the slabs), 2 = a second kernel (what splitk_phase 1 / 2 lets a caller
+ * issue as two launches of its own).  -1: invalid descriptor.  Host-only query. */
+int vt_conv2d_splitk_mode(const vt_conv_desc* desc);
 
 /* Plain conv weight (cout, cin_src, kh, kw) fp32 -> packed [cout][kh*kw][cin_dst],
  * multiplied by `scale` (EqualConv2d's 1/sqrt(fan_in), model/stylegan/model.py:101,117).

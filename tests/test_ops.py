@@ -437,6 +437,36 @@ def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
         assert torch.equal(a, b), hint
         assert int(ws.view(torch.int32)[:4096].abs().max()) == 0   # ticket area left zero
 
+    # thin outputs (masks, ToRGB, fusion_skip: cout <= 8) finish in the slice launch BY DEFAULT
+    import ctypes as C
+    from vtoonify_amd import _lib
+    lib = _lib.lib()
+    w3 = (g.standard_normal((3, 256, 3, 3)) / 40).astype(np.float32)
+    w3p = K.pack_conv_weight(T(w3, dev), out_dtype=torch.bfloat16)
+    bias = T(g.standard_normal(3).astype(np.float32), dev)
+
+    def thin():
+        out = torch.zeros((1, 3, 8, 8), dtype=torch.float32, device=dev)
+        d = K.make_conv_desc(src0=xt, c0=256, ld0=256, n=1, h=8, w=8, out_h=8, out_w=8, weight=w3p, cout=3, kh=3, kw=3,
+                             pad=1, bias=bias, out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32,
+                             dtype=K.VT_BF16, splitk_ws=ws)
+        mode = lib.vt_conv2d_splitk_mode(C.byref(d))
+        assert (lib.vt_conv2d_tile(C.byref(d)) // 1000000) % 100 > 1     # really split
+        _lib.check(lib.vt_conv2d(C.byref(d), K._stream(out)), "conv")
+        return out, mode
+
+    a, mode = thin()
+    assert mode == 1
+    assert torch.equal(thin()[0], a)
+    monkeypatch.setenv("VT_SPLITK_IN_LAUNCH", "0")
+    b, mode = thin()
+    monkeypatch.delenv("VT_SPLITK_IN_LAUNCH")
+    assert mode == 2 and torch.equal(a, b)
+    assert int(ws.view(torch.int32)[:4096].abs().max()) == 0
+    ref = torch.nn.functional.conv2d(xt.float().permute(0, 3, 1, 2).cpu(), w3p.float().view(3, 3, 3, 256).permute(0, 3, 1, 2).cpu(),
+                                     bias.cpu(), padding=1)
+    assert rel_err(a.cpu().numpy(), ref.numpy()) < 1e-5
+
 
 def test_conv_concat_prologue_transposed(dev):
     g = np.random.default_rng(0)

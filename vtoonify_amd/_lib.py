@@ -83,6 +83,7 @@ _SIGS = {
     "vt_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "vt_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "vt_conv2d_ws_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "vt_conv2d_splitk_mode": (C.c_int, [C.POINTER(ConvDesc)]),
     "vt_conv_weight_stream_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "vt_conv_tile_stats_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vt_conv_weight_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -418,11 +418,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                 if (m >= 0 && n < p.ldp) {
                     const float* src = p.partial + (int64_t)m * p.ldp + n;
                     unpack16<float>(ld128(src), f);
-                    for (int s = 1; s < p.splitk; ++s) {
-                        float g[4];
-                        unpack16<float>(ld128(src + s * slab), g);
+                    constexpr int SG = 8;   // slabs per memory round trip (summed in slice order all the same)
+                    for (int s0 = 1; s0 < p.splitk; s0 += SG) {
+                        float g[SG][4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) f[i] += g[i];
+                        for (int k = 0; k < SG; ++k)
+                            unpack16<float>(ld128(src + ((s0 + k < p.splitk) ? s0 + k : 0) * slab), g[k]);
+#pragma unroll
+                        for (int k = 0; k < SG; ++k) {
+                            if (s0 + k < p.splitk) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) f[i] += g[k][i];
+                            }
+                        }
                     }
                 }
 #pragma unroll
@@ -1522,15 +1530,23 @@ static bool glds_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
-// split-K finishing mode.  Default: the separate conv_splitk_reduce_kernel (6 us per conv).  The
-// in-launch form (last-arriving slice reduces, VT_SPLITK_IN_LAUNCH=1) is correct and deterministic
-// but measured 2x SLOWER on MI355X for these shapes (64-128 KB of slabs per tile: the per-workgroup
-// agent-scope release writes back the XCD's dirty L2 lines, ~6 us each, serialised per CU) -- kept
-// for A/B runs and for shapes with tiny slabs.
+// split-K finishing mode.  Two forms, both deterministic (slabs are summed in slice order):
+//   * two-pass: a separate conv_splitk_reduce_kernel -- the default for the wide convs.  For 64-128 KB of slabs
+//     per tile the in-launch form measured 2x SLOWER on MI355X (the per-workgroup agent-scope release writes
+//     back the XCD's dirty L2 lines, ~6 us each, serialised per CU);
+//   * in-launch: the slice that arrives last at the tile's ticket reduces -- the default for THIN outputs
+//     (cout <= 8: masks, ToRGB, fusion_skip; a tile's slabs are a few KB), where a second launch costs more
+//     (~6 us of dispatch per launch in a frame of ~100) than the fence.
+// VT_SPLITK_IN_LAUNCH=1 / 0 forces one form for every conv (A/B runs).  An explicit two-pass call
+// (vt_conv_desc.splitk_phase 1 / 2) never uses tickets.  vt_conv2d_splitk_mode() reports the choice.
+static bool in_launch_rule(const ConvArgs& a, int64_t ntile) {
+    if (a.phase != 0 || ntile * 4 > VT_TICKET_BYTES) return false;
+    const char* e = getenv("VT_SPLITK_IN_LAUNCH");   // read per call: tests flip it at run time
+    if (e && e[0]) return e[0] == '1';
+    return a.coutT <= 8;
+}
 static void split_mode(ConvArgs& args) {
-    const int64_t ntile = (int64_t)args.tiles_m * args.tiles_n;
-    const char* inl = getenv("VT_SPLITK_IN_LAUNCH");
-    if (args.splitk <= 1 || ntile * 4 > VT_TICKET_BYTES || !(inl && inl[0] == '1')) args.tickets = nullptr;
+    if (args.splitk <= 1 || !in_launch_rule(args, (int64_t)args.tiles_m * args.tiles_n)) args.tickets = nullptr;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -2096,6 +2112,20 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
         kind = glds ? 2 : 0;
     }
     return kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
+}
+
+extern "C" int vt_conv2d_splitk_mode(const vt_conv_desc* d) {
+    ConvArgs a;
+    if (fill_args(d, a) != VT_OK) return -1;
+    a.force_generic = d->tile_hint >= 1000000000;
+    a.phase = d->splitk_phase;
+    const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
+    const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
+                                           : choose_plan<float>(a, d->tile_hint % 1000000000, wsf);
+    if (t.splitk <= 1) return 0;
+    // the tile grid of the launch (launch_cfg / launch_patch): 1-D tiles of bm pixels, or bm/16 x 16-pixel tiles
+    const int64_t tiles_m = t.kind == 1 ? (int64_t)a.N * vt_cdiv(a.Ho, t.bm / 16) * vt_cdiv(a.Wo, 16) : vt_cdiv(a.M, t.bm);
+    return in_launch_rule(a, tiles_m * vt_cdiv(a.coutT, t.bn)) ? 1 : 2;
 }
 
 extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {

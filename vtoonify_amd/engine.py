@@ -87,10 +87,13 @@ class VToonifyEngine:
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
         self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
-        # style path on a second stream / graph branch beside the encoder (VT_STYLE_FORK=0: one stream)
-        self.fork_style = os.environ.get("VT_STYLE_FORK", "1") != "0"
+        # style path on a second stream / graph branch beside the encoder.  OFF by default: measured on one box
+        # (same call) one frame in flight +1 % (style) / +5 % (style + thin), but three frames in flight -31 % /
+        # -20 % -- forked graphs of several lanes collide on the graph's internal streams.  VT_STYLE_FORK=1 /
+        # VT_THIN_FORK=1 turn them on for a latency-bound single-stream caller.
+        self.fork_style = os.environ.get("VT_STYLE_FORK", "0") != "0"
         # RGB-skip path (fusion_skip conv, skip up-sampling, encoder ToRGB) on a third stream / branch
-        self.fork_thin = os.environ.get("VT_THIN_FORK", "1") != "0"
+        self.fork_thin = os.environ.get("VT_THIN_FORK", "0") != "0"
         # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
         # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
         self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
@@ -679,9 +682,10 @@ class VToonifyEngine:
                      3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel", 5: "conv_upblur_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
-            if sk > 1:
+            if sk > 1 and self.lib.vt_conv2d_splitk_mode(C.byref(d)) == 2:
                 # two-pass split-K as two plan ops (slices, reduce): each is one GPU kernel, so the
-                # per-kernel timings of bench.py line up with rocprofv3's kernel names
+                # per-kernel timings of bench.py line up with rocprofv3's kernel names.  (Thin outputs --
+                # masks, ToRGB, fusion_skip -- finish inside the slice launch: mode 1, one op.)
                 d.splitk_phase = 1
                 d2 = _lib.ConvDesc.from_buffer_copy(d)
                 d2.splitk_phase = 2
