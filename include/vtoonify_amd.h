@@ -131,8 +131,8 @@ typedef struct vt_conv_desc {
                               (every launch leaves them zero).  Small-M /                            */
     int64_t splitk_ws_bytes; /* small-cout convs with a deep K are cut along K into slices that run
                               as separate workgroups and are summed in slice order (deterministic) by a
-                              second kernel, or -- thin outputs, cout <= 8 -- by the last slice to arrive
-                              (vt_conv2d_splitk_mode()); vt_conv2d_ws_bytes() says how much the heuristic wants */
+                              second kernel (or by the last slice to arrive, VT_SPLITK_IN_LAUNCH=1: slower on MI355X,
+                              see vt_conv2d_splitk_mode()); vt_conv2d_ws_bytes() says how much the heuristic wants */
     const float* slope_vec; /* optional per-output-channel negative slope [cout] for VT_ACT_LRELU
                               (nn.PReLU of the pSp encoder, model/encoder/encoders/helpers.py:97-119);
                               NULL = the scalar `slope` */

@@ -437,7 +437,7 @@ def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
         assert torch.equal(a, b), hint
         assert int(ws.view(torch.int32)[:4096].abs().max()) == 0   # ticket area left zero
 
-    # thin outputs (masks, ToRGB, fusion_skip: cout <= 8) finish in the slice launch BY DEFAULT
+    # a thin output (mask / ToRGB / fusion_skip shape, planar fp32): both forms, and the host query that names them
     import ctypes as C
     from vtoonify_amd import _lib
     lib = _lib.lib()
@@ -455,13 +455,13 @@ def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
         _lib.check(lib.vt_conv2d(C.byref(d), K._stream(out)), "conv")
         return out, mode
 
-    a, mode = thin()
-    assert mode == 1
-    assert torch.equal(thin()[0], a)
-    monkeypatch.setenv("VT_SPLITK_IN_LAUNCH", "0")
     b, mode = thin()
+    assert mode == 2                              # default: slices + reduce kernel
+    monkeypatch.setenv("VT_SPLITK_IN_LAUNCH", "1")
+    a, mode = thin()
+    assert mode == 1 and torch.equal(thin()[0], a)
     monkeypatch.delenv("VT_SPLITK_IN_LAUNCH")
-    assert mode == 2 and torch.equal(a, b)
+    assert torch.equal(a, b)
     assert int(ws.view(torch.int32)[:4096].abs().max()) == 0
     ref = torch.nn.functional.conv2d(xt.float().permute(0, 3, 1, 2).cpu(), w3p.float().view(3, 3, 3, 256).permute(0, 3, 1, 2).cpu(),
                                      bias.cpu(), padding=1)

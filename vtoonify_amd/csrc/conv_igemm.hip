@@ -1531,19 +1531,18 @@ static bool glds_eligible(const ConvArgs& a, GldsArgs& g) {
 }
 
 // split-K finishing mode.  Two forms, both deterministic (slabs are summed in slice order):
-//   * two-pass: a separate conv_splitk_reduce_kernel -- the default for the wide convs.  For 64-128 KB of slabs
-//     per tile the in-launch form measured 2x SLOWER on MI355X (the per-workgroup agent-scope release writes
-//     back the XCD's dirty L2 lines, ~6 us each, serialised per CU);
-//   * in-launch: the slice that arrives last at the tile's ticket reduces -- the default for THIN outputs
-//     (cout <= 8: masks, ToRGB, fusion_skip; a tile's slabs are a few KB), where a second launch costs more
-//     (~6 us of dispatch per launch in a frame of ~100) than the fence.
-// VT_SPLITK_IN_LAUNCH=1 / 0 forces one form for every conv (A/B runs).  An explicit two-pass call
-// (vt_conv_desc.splitk_phase 1 / 2) never uses tickets.  vt_conv2d_splitk_mode() reports the choice.
+//   * two-pass (default): a separate conv_splitk_reduce_kernel;
+//   * in-launch (VT_SPLITK_IN_LAUNCH=1, A/B runs): the slice that arrives last at the tile's ticket reduces.
+//     Measured slower on MI355X for EVERY shape of the frame: 2x for the wide convs (64-128 KB of slabs per
+//     tile; the per-workgroup agent-scope release writes back the XCD's dirty L2 lines, ~6 us each), and for the
+//     thin ones too (masks / ToRGB / fusion_skip, a few KB of slabs per tile: 17.6 -> 19.4, 9.9 -> 12.6,
+//     17.9 -> 27.6 us per conv against slices + reduce kernel; whole frame -3 %, same-box A/B, round 2).
+// An explicit two-pass call (vt_conv_desc.splitk_phase 1 / 2) never uses tickets.  vt_conv2d_splitk_mode()
+// reports the choice.
 static bool in_launch_rule(const ConvArgs& a, int64_t ntile) {
     if (a.phase != 0 || ntile * 4 > VT_TICKET_BYTES) return false;
     const char* e = getenv("VT_SPLITK_IN_LAUNCH");   // read per call: tests flip it at run time
-    if (e && e[0]) return e[0] == '1';
-    return a.coutT <= 8;
+    return e && e[0] == '1';
 }
 static void split_mode(ConvArgs& args) {
     if (args.splitk <= 1 || !in_launch_rule(args, (int64_t)args.tiles_m * args.tiles_n)) args.tickets = nullptr;
