@@ -240,6 +240,37 @@ def test_conv_shapes(dev, dtype):
     assert _conv_case(dev, dtype, 1, 8, 1, 1, 8, 3, 1, 1, 1) < t                  # single pixel
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_thin_kernel(dev, dtype):
+    """conv_thin.hpp (KIND 6 of vt_conv2d_tile): cout <= 3, planar output, 3x3 / 1x1 -- the ToRGB, Fusion-mask and
+    fusion_skip convs (vtoonify.py:111,126,176,197-198; model.py:383-392) as one launch in the scatter form
+    (GEMM over the input pixels with taps*cout virtual channels, then a 9-term stencil).  Tile edges (sizes that
+    are not multiples of 8), batches, K-steps that do not divide by the 4 wavefronts, residual, relu+tanh."""
+    import ctypes
+    from vtoonify_amd import _lib
+    t = F32_TOL if dtype == torch.float32 else 8e-3
+    RT = K.ACT_RELU_TANH
+    kstep = 16 if dtype == torch.float32 else 32
+    x0 = torch.zeros((1, 8, 8, 4 * kstep), dtype=dtype, device=dev)
+    w0 = torch.zeros((3, 9, 4 * kstep), dtype=dtype, device=dev)
+    o0 = torch.zeros((1, 3, 8, 8), dtype=torch.float32, device=dev)
+    d = K.make_conv_desc(src0=x0, c0=4 * kstep, ld0=4 * kstep, n=1, h=8, w=8, out_h=8, out_w=8, weight=w0, cout=3, kh=3,
+                         kw=3, pad=1, out=o0, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, dtype=K.dt_code(dtype))
+    assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == 6
+    for (N, Cin, H, W, Cout, k, act, resid) in [
+            (1, 4 * kstep, 8, 8, 1, 3, RT, False),          # mask conv, one tile
+            (2, 5 * kstep, 11, 13, 3, 3, 0, True),          # fusion_skip-like: 27 virtual channels, edges, batch 2
+            (1, 18 * kstep, 9, 7, 3, 3, 0, False),          # 18 K-steps over 4 waves (576 channels in bf16)
+            (1, 2 * kstep, 5, 20, 2, 3, 0, False),          # fewer K-steps than wavefronts; cout 2
+            (2, 4 * kstep, 7, 5, 3, 1, 0, True),            # ToRGB: 1x1 + bias + up-sampled skip (residual)
+            (1, 9 * kstep, 16, 8, 1, 1, 0, False)]:
+        pad = k // 2
+        e_new = _conv_case(dev, dtype, N, Cin, H, W, Cout, k, 1, pad, 1, act=act, resid=resid, planar=True, seed=Cin + H)
+        e_old = _conv_case(dev, dtype, N, Cin, H, W, Cout, k, 1, pad, 1, act=act, resid=resid, planar=True, seed=Cin + H,
+                           hint=128016, ws=True)
+        assert e_new < t and e_old < t, (N, Cin, H, W, Cout, k, e_new, e_old)
+
+
 @pytest.mark.parametrize("hint", [128128, 128064, 128032, 128016, 64064, 64128, 32064])
 def test_conv_every_tile(dev, hint):
     for dtype in (torch.float32, torch.bfloat16):

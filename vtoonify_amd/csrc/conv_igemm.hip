@@ -1296,6 +1296,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 
 #include "conv_fullk.hpp"
 #include "conv_upblur.hpp"
+#include "conv_thin.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -1619,7 +1620,8 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 //   P 2 (hint only) = never use the patch kernel;  S = split-K slices (0 = auto in a hint)
 // ---------------------------------------------------------------------------------------
 struct TilePlan {
-    int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp)
+    int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp),
+               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp)
     int bm, bn, splitk;
 };
 
@@ -1688,6 +1690,20 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     }
     const int hp = (hint / 100000000) % 10;
     const int hs = (hint / 1000000) % 100, hbm = (hint / 1000) % 1000, hbn = hint % 1000;
+    {
+        // thin outputs (cout <= 3, planar): one launch, K over the wavefronts of a workgroup, no slabs
+        static const bool thin_on = [] {   // VT_THIN_KERNEL=0: the tile kernels + split-K instead (A/B)
+            const char* e = getenv("VT_THIN_KERNEL");
+            return !(e && e[0] == '0');
+        }();
+        if ((hp == 6 || (thin_on && hp == 0 && hbm == 0 && hs == 0)) && thin_eligible<T>(a)) {
+            t.kind = 6;
+            t.bm = TH_TW * TH_TW;
+            t.bn = a.taps * a.coutT > 16 ? 32 : 16;
+            t.splitk = 1;
+            return t;
+        }
+    }
     const int m1 = a.Ho * a.Wo;  // rows of one image
     auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(m1, m) * vt_cdiv(a.coutT, n); };
     auto ptiles = [&](int th, int n) {
@@ -1916,6 +1932,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         vt_set_error("vt_conv2d: in_tile_stats (AdaIN prologue) supports a single source");
         return VT_ERR_UNSUPPORTED;
     }
+    if (t.kind == 6) return launch_thin<T>(a, stream);
     if (t.kind == 4) {
         FullkArgs fg;
         if (!fullk_eligible<T>(a, a.wstream, fg)) {

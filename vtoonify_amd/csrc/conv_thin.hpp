@@ -1,0 +1,167 @@
+// Thin convolutions: 1x1 / 3x3, stride 1, cout <= 3, planar fp32 output -- the ToRGB convs below the fused levels,
+// the Fusion mask conv (2C -> 1, vtoonify.py:111,126) and fusion_skip (C+3 -> 3, vtoonify.py:197-198,262) and the
+// encoder's RGB head (vtoonify.py:176).  Included by conv_igemm.hip inside its anonymous namespace.
+//
+// Per frame these are 11 convs of 1-10 MFLOP over 2-33 MB of activations.  As GEMMs they have N = 1..3: the tile
+// kernels ran them with 16 output columns, cut K into 4-16 slices to find some parallelism and paid a second
+// (reduce) launch -- 10-18 us a conv, 160 us a frame.  Here the contraction is turned around ("scatter form"):
+//
+//     d[p][tap][co] = sum_c W[co][tap][c] * x[p][c]            one GEMM over the INPUT pixels p of the patch,
+//                                                               N = taps * cout <= 27 virtual channels (2 MFMA
+//                                                               fragments), every activation read once from
+//                                                               global memory straight into MFMA fragments
+//     out[q][co]    = sum_tap d[q + tap - 1][tap][co]           9-term stencil over the small d tile in LDS
+//
+// Zero padding is "pixels outside the image contribute d = 0".  A workgroup = one 8x8-pixel output tile (10x10
+// patch = 7 fragments of 16 pixels; 8x8 = 4 fragments for 1x1), 4 wavefronts, each taking every 4th K-step of
+// 4*VEC channels for all pixel fragments; the four partial d tiles meet in LDS and are summed in wave order
+// (deterministic).  No split-K workspace, no second launch.
+#pragma once
+
+constexpr int TH_TW = 8;            // output tile edge
+constexpr int TH_NW = 4;            // wavefronts = K-slices
+constexpr int TH_MAXF = 7;          // pixel fragments of a 10x10 patch
+constexpr int TH_COLS = 32;         // most virtual channels (taps * cout, padded): two 16-row weight fragments
+constexpr int TH_PADC = 4;          // floats of padding per d row (LDS banks)
+
+template <typename T>
+static bool thin_eligible(const ConvArgs& a) {
+    constexpr int KSTEP = 4 * (16 / (int)sizeof(T));
+    if (a.force_generic || a.transposed || a.in_scale || a.rgb_w || a.stats_part || a.tile_stats || a.in_tile_stats ||
+        a.up_fir || a.slope_vec)
+        return false;
+    if (a.out_layout != VT_OUT_NCHW || a.phases != 1 || a.stride != 1 || a.dil != 1) return false;
+    if (!((a.taps == 9 && a.kw == 3 && a.pad == 1) || (a.taps == 1 && a.pad == 0))) return false;
+    if (a.coutT < 1 || a.coutT > 3 || a.taps * a.coutT > TH_COLS) return false;
+    if (a.c1 != 0 || a.c0 % KSTEP != 0 || a.ld0 % (16 / (int)sizeof(T)) != 0) return false;
+    if (a.Ho != a.H || a.Wo != a.W) return false;
+    if ((uintptr_t)a.src0 % 16 != 0 || (uintptr_t)a.wgt % 16 != 0) return false;
+    return (int64_t)a.N * a.H * a.W * a.ld0 * (int64_t)sizeof(T) < ((int64_t)1 << 40);
+}
+
+template <typename T, int KS, int NB>   // KS = 3 (3x3, pad 1) or 1 (1x1); NB = weight fragments (16 virtual channels each)
+__global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KSTEP = 4 * VEC;                   // channels per MFMA K-step (lane group q owns VEC of them)
+    constexpr int PW = TH_TW + KS - 1;               // patch edge: 10 or 8
+    constexpr int NPIX = PW * PW;
+    constexpr int NF = (NPIX + 15) / 16;             // pixel fragments: 7 or 4
+    constexpr int TAPS = KS * KS;
+    constexpr int UNR = KS == 3 ? 3 : 4;             // K-steps in flight per wave (NF * UNR 16-byte loads per lane)
+    __shared__ __attribute__((aligned(16))) float dpart[TH_NW][NF * 16][16 * NB + TH_PADC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (TH_NW - 1);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int tiles_x = (p.W + TH_TW - 1) / TH_TW, tiles_y = (p.H + TH_TW - 1) / TH_TW;
+    const int img = blockIdx.x / (tiles_x * tiles_y);
+    const int trem = blockIdx.x - img * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH_TW, x0 = (trem % tiles_x) * TH_TW;
+    const int ncols = TAPS * p.coutT;
+
+    // this lane's pixel of every fragment (patch pixel f*16 + l15) -> element offset of its channel group, or -1
+    const T* src = (const T*)p.src0;
+    int64_t poff[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int pp = f * 16 + l15;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 + py - (KS / 2), ix = x0 + px - (KS / 2);
+        const bool in = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[f] = in ? ((int64_t)(img * p.H + iy) * p.W + ix) * p.ld0 + q * VEC : -1;
+    }
+    // this lane's weight row of both fragments: virtual channel v = b*16 + l15 = tap * cout + co
+    const T* wg = (const T*)p.wgt;
+    int64_t woff[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int v = b * 16 + l15;
+        const int tap = v / p.coutT, co = v - tap * p.coutT;
+        woff[b] = v < ncols ? ((int64_t)co * TAPS + tap) * p.cin + q * VEC : -1;
+    }
+
+    f32x4 acc[NF][NB];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[f][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const u128 zero = u128{0u, 0u, 0u, 0u};
+    const int nk = p.cin / KSTEP;
+    for (int k0 = wave; k0 < nk; k0 += TH_NW * UNR) {
+        u128 fa[UNR][NF], fw[UNR][NB];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int ks = k0 + u * TH_NW;
+            const bool live = ks < nk;
+            const int kb = (live ? ks : k0) * KSTEP;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Mma<T>::run(acc[f][b], fw[u][b], fa[u][f]);
+        }
+    }
+    // partial d tile of this wave: pixel f*16 + l15, virtual channels b*16 + 4q .. +3
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float v4[4] = {acc[f][b][0], acc[f][b][1], acc[f][b][2], acc[f][b][3]};
+            st128(&dpart[wave][f * 16 + l15][b * 16 + q * 4], pack16<float>(v4));
+        }
+    __syncthreads();
+
+    // stencil + epilogue: thread = (output pixel, output channel)
+    const int opix = tid & 63, co = tid >> 6;
+    const int oy = opix / TH_TW, ox = opix - oy * TH_TW;
+    const int gy = y0 + oy, gx = x0 + ox;
+    if (co >= p.coutT || gy >= p.H || gx >= p.W) return;
+    float s = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int pp = (oy + ky) * PW + ox + kx;        // patch pixel under this tap
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < TH_NW; ++w) t += dpart[w][pp][tap * p.coutT + co];   // K-slices in wave order
+        s += t;
+    }
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    const float v = conv_finish(p, s, p.bias ? p.bias[co] : 0.0f, ga, p.slope);
+    const int64_t HoWo = (int64_t)p.H * p.W;
+    const int64_t off = ((int64_t)img * p.cout + co) * HoWo + (int64_t)gy * p.W + gx;
+    const float* rs = (const float*)p.resid;
+    ((float*)p.out)[off] = post_act(p, v + (rs ? p.beta * rs[off] : 0.0f));
+}
+
+template <typename T>
+int launch_thin(const ConvArgs& a, vt_stream stream) {
+    ConvArgs args = a;
+    args.splitk = 1;
+    args.kps = 0;
+    const int64_t blocks = (int64_t)a.N * vt_cdiv(a.H, TH_TW) * vt_cdiv(a.W, TH_TW);
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    const bool two = a.taps * a.coutT > 16;
+    if (a.taps == 9 && two) {
+        auto k = conv_thin_kernel<T, 3, 2>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
+    } else if (a.taps == 9) {
+        auto k = conv_thin_kernel<T, 3, 1>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
+    } else {
+        auto k = conv_thin_kernel<T, 1, 1>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
+    }
+    return vt_check_launch("vt_conv2d(thin)");
+}
