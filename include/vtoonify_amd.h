@@ -376,6 +376,25 @@ int vt_corr_lookup(float* corr, const float* fmap1, const float* fmap2, const fl
                    vt_stream stream);
 int vt_avgpool2x2(float* out, const float* x, int n, int h, int w, int c, vt_stream stream);
 
+/* ---------------------------------------------------------------------------------
+ * Flow warp and temporal fusion of parsing maps -- the loop body of the flicker-reduction pre-pass
+ * (smooth_parsing_map.py:37-75 `warp`, :143-167).  fp32 NCHW planes, like the reference's tensors.
+ *   vt_flow_warp: x (n,c,h,w), flo (n,2,h,w) = (dx, dy) -> out (n,c,h,w) = mask * grid_sample(x, grid + flo,
+ *     bilinear, zeros, align_corners=True), mask (n,h,w) or NULL = 1 where grid_sample(ones) >= 0.9999 else 0
+ *     (smooth_parsing_map.py:58-73; the reference returns the mask broadcast over c).
+ *   vt_parsing_fuse: one centre frame against a window of `wn` frames (wn = 2*window+1, :155-166):
+ *     frames (wn,3,h,w) = image2, center (3,h,w) = image1, parsing (wn,cp,h,w), flow (wn,2,h,w) = RAFT's flow_up,
+ *     wt (wn) temporal weights (:140) -> fused (cp,h,w) = sum_j aligned_P_j w_j / sum_j w_j with
+ *     w_j = wt_j * exp(-mean_c (aligned_I_j - image1)^2 / (2 sigma^2)) * mask_j, and for j = center_index
+ *     aligned_P = parsing[center_index], w = wt_j (:161-163).  sigma = 0.2 in the reference.  cp <= 32.
+ *     The caller finishes with Downsample = vt_upfirdn2d(down 2, pad (1,1)) (:108,167).
+ * --------------------------------------------------------------------------------- */
+int vt_flow_warp(float* out, float* mask, const float* x, const float* flo, int n, int c, int h, int w,
+                 vt_stream stream);
+int vt_parsing_fuse(float* fused, const float* frames, const float* center, const float* parsing,
+                    const float* flow, const float* wt, int wn, int center_index, int cp, int h, int w,
+                    float sigma, vt_stream stream);
+
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,
                     int in_dtype, int out_dtype, vt_stream stream);

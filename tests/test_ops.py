@@ -480,7 +480,7 @@ def test_conv_splitk_in_launch_equals_two_pass(dev, monkeypatch):
         out = torch.zeros((1, 3, 8, 8), dtype=torch.float32, device=dev)
         d = K.make_conv_desc(src0=xt, c0=256, ld0=256, n=1, h=8, w=8, out_h=8, out_w=8, weight=w3p, cout=3, kh=3, kw=3,
                              pad=1, bias=bias, out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32,
-                             dtype=K.VT_BF16, splitk_ws=ws)
+                             dtype=K.VT_BF16, splitk_ws=ws, tile_hint=128016)   # (no hint: the thin kernel, no split)
         mode = lib.vt_conv2d_splitk_mode(C.byref(d))
         assert (lib.vt_conv2d_tile(C.byref(d)) // 1000000) % 100 > 1     # really split
         _lib.check(lib.vt_conv2d(C.byref(d), K._stream(out)), "conv")

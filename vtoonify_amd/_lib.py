@@ -120,6 +120,8 @@ _SIGS = {
                            [C.c_float, C.c_void_p]),
     "vt_corr_lookup": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_void_p]),
     "vt_avgpool2x2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "vt_flow_warp": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "vt_parsing_fuse": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
