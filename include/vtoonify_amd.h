@@ -188,7 +188,7 @@ typedef struct vt_conv_desc {
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
-/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel, 4 whole-K kernel, 5 conv_transpose+blur kernel, 6 thin-output kernel; -1: invalid descriptor).
+/* The workgroup tile vt_conv2d would run `desc` on, as KIND*100000000+SPLITK*1000000+BM*1000+BN (KIND 0 register-staged, 1 patch-resident, 2 direct-to-LDS, 3 persistent 32->32 kernel, 4 whole-K kernel, 5 conv_transpose+blur kernel, 6 thin-output kernel, 7 persistent 64->64 kernel; -1: invalid descriptor).
  * Host-only query (no launch); lets a profiler name the kernel instance of each launch. */
 int vt_conv2d_tile(const vt_conv_desc* desc);
 /* Bytes of split-K workspace vt_conv2d would like for `desc` (0: it would not split). */

@@ -320,7 +320,8 @@ def test_conv_fused_torgb(dev, dtype):
     for cin, cout, H, W, hint in [(64, 128, 19, 37, P + 1000000 + 256128),      # patch, 8 waves, channels over 2 waves
                                   (64, 64, 21, 35, P + 1000000 + 256064),
                                   (64, 64, 9, 40, P + 1000000 + 128064),
-                                  (32, 32, 17, 33, 0),                          # register-staged 128x32 (4 waves x 1)
+                                  (32, 32, 17, 33, 0),                          # persistent 32->32 kernel (bf16) / tile kernel
+                                  (64, 64, 23, 41, 0),                          # persistent 64->64 kernel (bf16): halves meet in LDS
                                   (64, 128, 12, 20, 2 * P + 1000000 + 128128)]:  # 1-D direct-to-LDS, 2x2 waves
         x = g.standard_normal((2, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(9 * cin)).astype(np.float32)
@@ -352,6 +353,28 @@ def test_conv_fused_torgb(dev, dtype):
         K.conv2d(src0=xt, c0=64, ld0=64, n=1, h=8, w=8, out_h=8, out_w=8, weight=wp, cout=256, kh=3, kw=3, pad=1,
                  out=torch.zeros((1, 8, 8, 256), dtype=dtype, device=dev), ld_out=256, dtype=K.dt_code(dtype),
                  rgb_weight=wrp, rgb_out=rgb)
+
+
+def test_conv_c64_persistent_kernel(dev, monkeypatch):
+    """3x3 64->64 bf16 (the 512^2 level, conv_c64.hpp, KIND 7): 8 wavefronts = 4 pixel quarters x 2 channel halves,
+    weights in registers, several tiles per workgroup (double-buffered patches), image borders, batch."""
+    t = 8e-3
+    import ctypes
+    from vtoonify_amd import _lib
+    x = K.nchw_to_nhwc(torch.zeros(1, 64, 16, 16, device=dev), torch.bfloat16)
+    d = K.make_conv_desc(src0=x, c0=64, ld0=64, n=1, h=16, w=16, out_h=16, out_w=16, weight=x, cout=64, kh=3, kw=3,
+                         pad=1, out=x, ld_out=64, dtype=K.VT_BF16)
+    assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == 7
+    monkeypatch.setenv("VT_C32_BLOCKS", "3")     # 2 x 3 x 4 = 24 tiles over 3 workgroups
+    assert _conv_case(dev, torch.bfloat16, 2, 64, 37, 50, 64, 3, 1, 1, 1, act=K.ACT_LRELU) < t
+    monkeypatch.delenv("VT_C32_BLOCKS")
+    assert _conv_case(dev, torch.bfloat16, 1, 64, 16, 16, 64, 3, 1, 1, 1) < t
+    assert _conv_case(dev, torch.bfloat16, 1, 64, 9, 30, 64, 3, 1, 1, 1, act=K.ACT_LRELU) < t
+    # residual epilogue, fp32, dilation: the generic kernels
+    assert _conv_case(dev, torch.bfloat16, 2, 64, 21, 18, 64, 3, 1, 1, 1, act=K.ACT_LRELU, resid=True) < t
+    assert _conv_case(dev, torch.float32, 1, 64, 19, 21, 64, 3, 1, 1, 1, act=K.ACT_LRELU) < F32_TOL
+    monkeypatch.setenv("VT_C64_KERNEL", "0")
+    assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == 7     # (read once per process: still on)
 
 
 def test_conv_c32_persistent_kernel(dev, monkeypatch):

@@ -1297,6 +1297,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #include "conv_fullk.hpp"
 #include "conv_upblur.hpp"
 #include "conv_thin.hpp"
+#include "conv_c64.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -1621,7 +1622,7 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 // ---------------------------------------------------------------------------------------
 struct TilePlan {
     int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp),
-               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp)
+               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp), 7 = persistent 64->64
     int bm, bn, splitk;
 };
 
@@ -1716,6 +1717,19 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         t.bn = 32;
         t.splitk = 1;
         return t;
+    }
+    {
+        static const bool c64_on = [] {   // VT_C64_KERNEL=0: the patch-resident tile kernel instead (A/B)
+            const char* e = getenv("VT_C64_KERNEL");
+            return !(e && e[0] == '0');
+        }();
+        if (c64_on && hp != 2 && hbm == 0 && c64_eligible<T>(a, g)) {   // the 512^2 level: the same, 64 channels
+            t.kind = 7;
+            t.bm = 256;
+            t.bn = 64;
+            t.splitk = 1;
+            return t;
+        }
     }
     {
         // whole-K kernel (conv_fullk.hpp): the layers the heuristics below would cut along K into fp32 slabs --
@@ -1940,6 +1954,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             return VT_ERR_UNSUPPORTED;
         }
         return launch_fullk<T>(a, fg, stream);
+    }
+    if (t.kind == 7) {
+        GldsArgs g;
+        if (!c64_eligible<T>(a, g)) {
+            vt_set_error("vt_conv2d: c64 kernel requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+        return launch_c64<T>(a, g, stream);
     }
     if (t.kind == 3) {
         GldsArgs g;
