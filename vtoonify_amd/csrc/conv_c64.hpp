@@ -29,26 +29,29 @@ static bool c64_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(512, 2)   // 8 waves = 2 per SIMD (<= 256 registers), one workgroup per CU
+// NWM = pixel-row groups of a workgroup (4 tile rows each): 4 -> 16x16-pixel tiles, 8 waves, one workgroup per CU;
+// 2 -> 8x16-pixel tiles, 4 waves, TWO workgroups per CU whose load / compute / store phases interleave (default)
+// PIPE = prefetch depth of the tap loop (see there)
+template <typename T, int NWM, int PIPE>
+__global__ void __launch_bounds__(NWM * 128, 2)   // 2 waves per SIMD (<= 256 registers)
 conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(sizeof(T) == 2, "bf16 only (128-byte pixel rows)");
-    constexpr int TH = 16, TW = 16;
+    constexpr int TH = 4 * NWM, TW = 16, NWAVES = 2 * NWM;
     constexpr int TM = 4, TN = 2;                                // per wave: 4 tile rows x 16 pixels, 2 x 16 channels
     // 18x18-pixel patch stored with a 24-pixel row pitch: every (tile row, tap row) offset is then a multiple of 8
     // pixels, the swizzle term (pixel & 7) depends on the lane and kx only, and the 72 fragment addresses of a tile
     // are 6 registers + immediate offsets (with an 18-pixel pitch LLVM kept 36+ loop-invariant addresses live next
     // to the 144 weight registers and spilled inside the tap loop)
     constexpr int PH = TH + 2, PW = TW + 2, PITCH = 24;
-    constexpr int NLOAD = PH * (PITCH / 8);                      // 8-pixel (1 KB) wave loads per tile: 54
-    constexpr int PA = (NLOAD + 7) / 8;                          // per wave: 7
-    constexpr int A_BYTES = PA * 8 * 1024;                       // 56 KB per buffer
+    constexpr int NLOAD = PH * (PITCH / 8);                      // 8-pixel (1 KB) wave loads per tile: 54 / 30
+    constexpr int PA = (NLOAD + NWAVES - 1) / NWAVES;            // per wave: 7 / 8
+    constexpr int A_BYTES = PA * NWAVES * 1024;                  // 56 / 32 KB per buffer
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES];
-    __shared__ float rgbx[4][TM][16][3];                         // ToRGB partials of the upper channel half
+    __shared__ float rgbx[NWM][TM][16][3];                       // ToRGB partials of the upper channel half
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = vt_uniform(tid >> 6) & 7;
+    const int wave = vt_uniform(tid >> 6) & (NWAVES - 1);
     const int wm = wave >> 1, wn = wave & 1;
     const int q = lane >> 4, l15 = lane & 15;
 
@@ -69,6 +72,13 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const int ntiles = p.N * tiles_x * tiles_y;
     const int lpix = lane >> 3, lslot = lane & 7;
+    struct Rows {   // tile pixel (row-major, 16 wide) -> global GEMM row m, or -1
+        int img, y0, x0, Ho, Wo;
+        __device__ __forceinline__ int operator()(int row) const {
+            const int oy = y0 + (row >> 4), ox = x0 + (row & 15);
+            return (oy < Ho && ox < Wo) ? (img * Ho + oy) * Wo + ox : -1;
+        }
+    };
 
     auto issue = [&](int tile, int buf) {
         const int img = tile / (tiles_x * tiles_y);
@@ -76,7 +86,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int li = i * 8 + wave;
+            const int li = i * NWAVES + wave;
             const int pr = li * 8 + lpix;             // linear patch pixel at the 24-pixel pitch
             const int py = pr / PITCH, px = pr - py * PITCH;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
@@ -84,7 +94,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
             const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
             // the lane that lands in physical slot s fetches the logical 16-byte chunk s ^ (pixel & 7)
             const uint32_t off = in ? pix * (uint32_t)(p.ld0 * 2) + ((uint32_t)(lslot ^ (pr & 7)) << 4) : GLDS_OOB;
-            vt_glds16(r0, smem + buf * A_BYTES + li * 1024, off, 0u);
+            if (p.dbg != 33) vt_glds16(r0, smem + buf * A_BYTES + li * 1024, off, 0u);   // (33: ablation, no patch loads)
         }
     };
 
@@ -110,7 +120,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
         const int img = tile / (tiles_x * tiles_y);
         const int trem = tile - img * (tiles_x * tiles_y);
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-        const PatchRows<TW> rowmap{img, y0, x0, p.Ho, p.Wo};
+        const Rows rowmap{img, y0, x0, p.Ho, p.Wo};
         const int HoWo = p.Ho * p.Wo;
         f32x4 acc[TM][TN];
 #pragma unroll
@@ -118,23 +128,33 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned char* sa = smem + buf * A_BYTES;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        // software pipeline: the 4 pixel fragments of K-half h+1 are read while the 8 MFMAs of K-half h issue
+        // (with the reads and MFMAs of one K-half fenced together the LDS latency was exposed 18 times per tile:
+        // the tap loop measured 3.5 us per tile, 14 of the kernel's 44 us)
+        auto read_a = [&](u128 (&fa)[TM], int h) {   // h = tap * 2 + kh, compile-time after unrolling
+            const int t = h >> 1, kh = h & 1;
             const int ky = t / 3, kx = t - ky * 3;
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                u128 fa[TM];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const int pr = (wm * TM + a + ky) * PITCH + kx + l15;
-                    fa[a] = ld128(sa + pr * 128 + (((kh * 4 + q) ^ ((kx + l15) & 7)) << 4));
-                }
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], wreg[t][kh][b], fa[a]);
-                vt_sched_fence();   // one K-half's fragments live at a time (the scheduler otherwise hoists every read)
+            for (int a = 0; a < TM; ++a) {
+                const int pr = (wm * TM + a + ky) * PITCH + kx + l15;
+                fa[a] = ld128(sa + pr * 128 + (((kh * 4 + q) ^ ((kx + l15) & 7)) << 4));
             }
+        };
+        u128 fa[2][TM];
+        if (PIPE) read_a(fa[0], 0);
+#pragma unroll
+        for (int h = 0; h < 18; ++h) {
+            if (p.dbg == 32) break;   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): no tap loop
+            if (PIPE) {
+                if (h + 1 < 18) read_a(fa[(h + 1) & 1], h + 1);
+            } else {
+                read_a(fa[h & 1], h);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], wreg[h >> 1][h & 1][b], fa[h & 1][a]);
+            vt_sched_fence();   // at most two K-halves' fragments live (the scheduler otherwise hoists every read)
         }
         // lean epilogue: bias + LeakyReLU * gain -> bf16 NHWC, optional fused ToRGB
         float r[TM][3];
@@ -187,7 +207,8 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
                         }
                     }
                 }
-                if (m >= 0) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + wn * 32 + q * 8, pack16<bf16_t>(f));
+                if (m >= 0 && !(p.dbg == 31 && f[0] != 123.456f))   // (31: ablation, no activation stores)
+                    st128((bf16_t*)p.out + (int64_t)m * p.ld_out + wn * 32 + q * 8, pack16<bf16_t>(f));
                 if (rgbf) {
                     r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
                     r1 += __shfl_xor(r1, 16, 64); r1 += __shfl_xor(r1, 32, 64);
@@ -231,14 +252,31 @@ int launch_c64(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     args.slab_perm = 0;
     args.splitk = 1;
     args.tiles_n = 1;
-    args.tiles_m = a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16);
-    int blocks = args.tiles_m < 256 ? args.tiles_m : 256;   // persistent: one 8-wave workgroup per CU
+    static const int rows = [] {   // VT_C64_ROWS=16: the 16x16-pixel / 8-wave form (A/B)
+        const char* e = getenv("VT_C64_ROWS");
+        return e && atoi(e) == 16 ? 16 : 8;
+    }();
+    args.tiles_m = a.N * vt_cdiv(a.Ho, rows) * vt_cdiv(a.Wo, 16);
+    const int cap = rows == 16 ? 256 : 512;                 // persistent: one 8-wave / two 4-wave workgroups per CU
+    int blocks = args.tiles_m < cap ? args.tiles_m : cap;
     if (const char* e = getenv("VT_C32_BLOCKS")) {          // tests: force several tiles per workgroup
         const int v = atoi(e);
         if (v > 0 && v < blocks) blocks = v;
     }
-    auto k = conv3x3_c64_kernel<bf16_t>;
     (void)sizeof(T);
-    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(512), stream, args, g);
+    static const int pipe = [] {   // VT_C64_PIPE=1: software-pipelined fragment reads (A/B)
+        const char* e = getenv("VT_C64_PIPE");
+        return e ? atoi(e) : 0;
+    }();
+    if (rows == 16) {
+        auto k = conv3x3_c64_kernel<bf16_t, 4, 0>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(512), stream, args, g);
+    } else if (pipe) {
+        auto k = conv3x3_c64_kernel<bf16_t, 2, 1>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    } else {
+        auto k = conv3x3_c64_kernel<bf16_t, 2, 0>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    }
     return vt_check_launch("vt_conv2d(c64)");
 }
