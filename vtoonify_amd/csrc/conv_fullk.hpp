@@ -223,6 +223,15 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
                 tab[BK + cl] = ad_shift;
             }
             vt_wave_sync();
+            // every lane owns the LOGICAL 16-byte chunk (lane & 7) of its pixel rows: scale / shift of its VEC channels
+            // are read once (the first version looked the physical slot's chunk up per row: 4 table reads x 13 rows)
+            float sc[VEC], sh[VEC];
+            const int jj = lane & 7;
+#pragma unroll
+            for (int k = 0; k < VEC; k += 4) {
+                unpack16<float>(ld128(tab + jj * VEC + k), sc + k);
+                unpack16<float>(ld128(tab + BK + jj * VEC + k), sh + k);
+            }
 #pragma unroll
             for (int i = 0; i < FK_PA; ++i) {
                 const int row = i * 8 + (lane >> 3);
@@ -230,17 +239,12 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
                 const int iy = y0 + (py - 1) * d, ix = x0 + (px - 1) * d;
                 const bool in = row < FK_PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 if (in) {
-                    const int jj = (lane & 7) ^ fk_swz(px);   // logical 16-byte chunk in this physical slot
-                    float f[VEC], sc[VEC], sh[VEC];
-                    unpack16<T>(ld128(my + i * 1024 + lane * 16), f);
+                    unsigned char* at = my + row * 128 + ((jj ^ fk_swz(px)) << 4);   // physical slot of the chunk
+                    float f[VEC];
+                    unpack16<T>(ld128(at), f);
 #pragma unroll
-                    for (int k = 0; k < VEC; k += 4) {   // 16-byte table reads (the scalar form cost 2 x VEC ds_reads)
-                        unpack16<float>(ld128(tab + jj * VEC + k), sc + k);
-                        unpack16<float>(ld128(tab + BK + jj * VEC + k), sh + k);
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) f[k] = f[k] * sc[k] + sh[k];
-                    st128(my + i * 1024 + lane * 16, pack16<T>(f));
+                    for (int k = 0; k < VEC; ++k) f[k] = fmaf(f[k], sc[k], sh[k]);
+                    st128(at, pack16<T>(f));
                 }
             }
             vt_wave_sync();

@@ -28,6 +28,7 @@
 struct UpblurArgs {
     uint32_t nrec0, nrecw;
     int tiles_y, tiles_x;     // output tiles per image
+    int skew;                 // VT_UPBLUR_SKEW experiment (0 = off)
 };
 
 template <typename T, int CN, int QY, int DB, int PERSIST, int LB2>
@@ -83,6 +84,13 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     const int per_img = g.tiles_y * g.tiles_x;
     const int n0 = tile_n * CN;
     const int OH = 2 * p.H, OW = 2 * p.W;
+#ifndef VT_EMU
+    // EXPERIMENT (VT_UPBLUR_SKEW=n, tools only): the second wave of workgroups (the second resident workgroup of every
+    // CU) starts n x 2.7 us late, so that the load / MFMA / blur phases of a CU's two workgroups stop coinciding
+    if (g.skew > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
 
     // ---- loader state: patch pixel (py, px) = input pixel (I0 - 2 + py, J0 - 2 + px) --------------------------
     const int lrow = lane >> 3;
@@ -395,6 +403,10 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
         if (per_n < 1) per_n = 1;
         if (per_n > args.tiles_m) per_n = args.tiles_m;
         blocks = (int64_t)per_n * args.tiles_n;
+    }
+    {
+        const char* e = getenv("VT_UPBLUR_SKEW");
+        g.skew = e ? atoi(e) : 0;
     }
     auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST, LB2>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);

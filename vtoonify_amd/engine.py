@@ -291,7 +291,6 @@ class VToonifyEngine:
         style_in = self._buf(plan, "style_in", (ns, N_LATENT, 512), f32)   # W+ rows
         ada = self._buf(plan, "adastyles", (ns, N_LATENT, 512), f32)
         ds = self._buf(plan, "d_s", (1,), f32)
-        ds1 = self._buf(plan, "d_s_rows", (ns, 1), f32)
         rows = ns * N_LATENT
         levels: List[list] = [[] for _ in range(5)]
 
@@ -362,12 +361,12 @@ class VToonifyEngine:
                         lin(2, gb, Wl.shape[0], plan.bufs["resstyles"].data_ptr() + ii * 512 * 4,
                             N_LATENT * 512, Wl, sd[f"res.{ii}.{nm}.style.bias"], ns)
             # Fusion: label = MLP(d_s) (vtoonify.py:114-124), then AdaIN linear(label)
-            ops.append((self._fill_rows_op, (ds1, ds), "fill"))
+            # (every row reads the one style degree: row stride 0 -- no broadcast copy)
             for fi in range(self.n_fuse):
                 p = f"fusion_out.{fi}."
                 l0 = self._buf(plan, f"lab0.{fi}", (ns, 64), f32)
                 l1 = self._buf(plan, f"lab1.{fi}", (ns, 128), f32)
-                lin(0, l0, 64, ds1, 1, sd[p + "linear.0.weight"], sd[p + "linear.0.bias"], ns,
+                lin(0, l0, 64, ds, 0, sd[p + "linear.0.weight"], sd[p + "linear.0.bias"], ns,
                     1.0, 1.0, ACT_LRELU, 0.2, 1.0)
                 lin(1, l1, 128, l0, 64, sd[p + "linear.2.weight"], sd[p + "linear.2.bias"], ns,
                     1.0, 1.0, ACT_LRELU, 0.2, 1.0)
