@@ -34,13 +34,13 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 2
+#define VT_ABI_VERSION 3
 
 enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
 
 /* activation codes of the fused epilogues */
-enum { VT_ACT_NONE = 0, VT_ACT_LRELU = 1, VT_ACT_RELU_TANH = 2, VT_ACT_SIGMOID = 3 /* vt_linear only */ };
+enum { VT_ACT_NONE = 0, VT_ACT_LRELU = 1, VT_ACT_RELU_TANH = 2, VT_ACT_SIGMOID = 3, VT_ACT_TANH = 4 /* conv epilogues: all; vt_linear: 0, 1, 3 */ };
 /* output layouts of vt_conv2d */
 enum { VT_OUT_NHWC = 0, VT_OUT_NCHW = 1 };
 
@@ -185,6 +185,10 @@ typedef struct vt_conv_desc {
      * ALUs out of LDS; the (2h+1)^2 intermediate never reaches HBM.  KIND 5 of vt_conv2d_tile.  kh = kw = 3,
      * phases = 1, single source, NHWC output in the compute dtype, no residual. */
     const float* up_fir;
+    /* ABI 3: horizontal padding + 1 when it differs from `pad` (0 = same as `pad`): the (1,5) / (5,1) convs of
+     * RAFT's SepConvGRU (model/raft/core/update.py:37-42: padding (0,2) / (2,0)); `pad` is then the vertical one.
+     * Such convs run on the register-staged kernel. */
+    int32_t pad_w_p1;
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);
@@ -394,6 +398,21 @@ int vt_flow_warp(float* out, float* mask, const float* x, const float* flo, int 
 int vt_parsing_fuse(float* fused, const float* frames, const float* center, const float* parsing,
                     const float* flow, const float* wt, int wn, int center_index, int cp, int h, int w,
                     float sigma, vt_stream stream);
+
+/* ---------------------------------------------------------------------------------
+ * RAFT glue (model/raft/core): everything between the convolutions of the optical-flow network.
+ *   vt_eltwise2: out = a op b on `rows` pixel rows of `c` channels with independent row strides (elements);
+ *     op 0 = a * b (r * h, update.py:48,54), 1 = a + b, 2 = relu(a + b) (ResidualBlock, extractor.py:53-60).
+ *   vt_gru_blend: h = (1 - z) * h + z * q in place (update.py:49,55); z, q contiguous, h with row stride ld_h.
+ *   vt_coords_from_flow: coords (n,1,h,w,2) = pixel grid + flow (n,2,h,w) (raft.py:58-66,121,127): the argument of
+ *     vt_corr_lookup.
+ *   vt_convex_upsample: RAFT.upsample_flow (raft.py:72-84): flow (n,2,h,w), mask (n,576,h,w) -> out (n,2,8h,8w).
+ * --------------------------------------------------------------------------------- */
+int vt_eltwise2(void* out, int ld_out, const void* a, int ld_a, const void* b, int ld_b, int64_t rows, int c,
+                int op, int dtype, vt_stream stream);
+int vt_gru_blend(void* h, int ld_h, const void* z, const void* q, int64_t rows, int c, int dtype, vt_stream stream);
+int vt_coords_from_flow(float* coords, const float* flow, int n, int h, int w, vt_stream stream);
+int vt_convex_upsample(float* out, const float* flow, const float* mask, int n, int h, int w, vt_stream stream);
 
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,

@@ -7,9 +7,10 @@
     model.stylegan.op (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix)
                                                               -> vtoonify_amd.op
     model.encoder.encoders.psp_encoders.GradualStyleEncoder   -> vtoonify_amd.psp
+    model.raft.core.raft.RAFT  (smooth_parsing_map.py:12)     -> vtoonify_amd.raft
 
 Putting this repository BEFORE the reference checkout on sys.path makes those imports resolve to the
-gfx950 implementations; every other submodule (`model.encoder.align_all_parallel`, `model.raft`, the
+gfx950 implementations; every other submodule (`model.encoder.align_all_parallel`, `model.raft.core.utils`, the
 training-only `model.stylegan.model` ...) still resolves to the reference checkout further down the
 path, because each mirrored package extends its `__path__` over all same-named directories
 (pkgutil.extend_path; the reference's own `__init__.py` files are empty).  Nothing here computes.

@@ -15,9 +15,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
-ABI_VERSION = 2   # VT_ABI_VERSION of include/vtoonify_amd.h
+ABI_VERSION = 3   # VT_ABI_VERSION of include/vtoonify_amd.h
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
-ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_NCHW = 0, 1
 
 
@@ -54,7 +54,7 @@ class ConvDesc(C.Structure):
         ("weight_stream", C.c_void_p),
         ("tile_stats", C.c_void_p), ("in_tile_stats", C.c_void_p), ("in_stats_dil", C.c_int32),
         ("in_gb", C.c_void_p), ("in_ld_gb", C.c_int32),
-        ("up_fir", C.c_void_p),
+        ("up_fir", C.c_void_p), ("pad_w_p1", C.c_int32),
     ]
 
 
@@ -122,6 +122,11 @@ _SIGS = {
     "vt_avgpool2x2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "vt_flow_warp": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "vt_parsing_fuse": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "vt_eltwise2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p]),
+    "vt_gru_blend": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "vt_coords_from_flow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vt_convex_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_fusion_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vt_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -62,7 +62,7 @@ struct ConvArgs {
     int c0, c1, ld0, ld1, cin;
     int N, H, W, Ho, Wo;
     int coutT, cout, K, taps, kw;
-    int stride, pad, dil, transposed, phases;
+    int stride, pad, pad_x, dil, transposed, phases;   // pad = vertical, pad_x = horizontal (vt_conv_desc.pad_w_p1)
     int act;
     float slope, gain_alpha, beta;
     int ld_res, ld_out, out_layout, out_f32, vec_store;
@@ -198,6 +198,8 @@ __device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float b
     v += bias;
     if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * slope;   // slope: scalar or per-channel (PReLU)
     else if (p.act == VT_ACT_RELU_TANH) v = tanhf(fmaxf(v, 0.0f));
+    else if (p.act == VT_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    else if (p.act == VT_ACT_TANH) v = tanhf(v);
     return v * ga;
 }
 
@@ -592,7 +594,7 @@ conv_igemm_kernel(const ConvArgs p) {
         a_img[i] = img;
         a_pix[i] = img * p.H * p.W;
         a_y[i] = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
-        a_x[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
+        a_x[i] = p.transposed ? ox + p.pad : ox * p.stride - p.pad_x;
     }
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt0 = split * p.kps;
@@ -1902,7 +1904,7 @@ int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
 template <typename T>
 int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) {
     ConvArgs a = a0;
-    a.force_generic = hint >= 1000000000;
+    a.force_generic = hint >= 1000000000 || a.pad_x != a.pad;
     const TilePlan t = choose_plan<T>(a, hint % 1000000000, ws_floats);
     a.splitk = t.splitk;
     a.ldp = slab_ld(a.coutT);
@@ -2098,6 +2100,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.K = a.taps * a.cin;
     a.stride = d->stride;
     a.pad = d->pad;
+    a.pad_x = d->pad_w_p1 > 0 ? d->pad_w_p1 - 1 : d->pad;
     a.dil = d->dil;
     a.transposed = d->transposed;
     a.phases = d->phases;
@@ -2139,7 +2142,7 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
 extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    a.force_generic = d->tile_hint >= 1000000000;
+    a.force_generic = d->tile_hint >= 1000000000 || a.pad_x != a.pad;
     const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
                                            : choose_plan<float>(a, d->tile_hint % 1000000000, wsf);
@@ -2155,7 +2158,7 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
 extern "C" int vt_conv2d_splitk_mode(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    a.force_generic = d->tile_hint >= 1000000000;
+    a.force_generic = d->tile_hint >= 1000000000 || a.pad_x != a.pad;
     a.phase = d->splitk_phase;
     const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     const TilePlan t = d->dtype == VT_BF16 ? choose_plan<bf16_t>(a, d->tile_hint % 1000000000, wsf)
@@ -2169,7 +2172,7 @@ extern "C" int vt_conv2d_splitk_mode(const vt_conv_desc* d) {
 extern "C" int64_t vt_conv2d_ws_bytes(const vt_conv_desc* d) {
     ConvArgs a;
     if (fill_args(d, a) != VT_OK) return -1;
-    a.force_generic = d->tile_hint >= 1000000000;
+    a.force_generic = d->tile_hint >= 1000000000 || a.pad_x != a.pad;
     float dummy;
     a.partial = &dummy;  // "a workspace of any size exists": report what the heuristic would use
     const int64_t big = (int64_t)1 << 40;

@@ -124,6 +124,91 @@ parsing_fuse_kernel(float* __restrict__ fused, const float* __restrict__ frames,
     }
 }
 
+// ---- RAFT glue (model/raft/core/update.py:44-56 SepConvGRU gates, raft.py:72-84 convex up-sampling, :58-66 coords) ----
+// out[r][c] = a op b on rows of `c` channels with independent row strides: 0 mul (r * h), 1 add, 2 relu(add)
+template <typename T>
+__global__ void __launch_bounds__(256)
+eltwise2_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ a, int ld_a, const T* __restrict__ b, int ld_b,
+                int64_t rows, int c, int op) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c;
+        const int ch = (int)(i - r * c);
+        const float x = to_f32(a[r * ld_a + ch]), y = to_f32(b[r * ld_b + ch]);
+        float v = op == 0 ? x * y : x + y;
+        if (op == 2) v = fmaxf(v, 0.0f);
+        out[r * ld_out + ch] = from_f32<T>(v);
+    }
+}
+
+// h = (1 - z) * h + z * q in place (update.py:49,55)
+template <typename T>
+__global__ void __launch_bounds__(256)
+gru_blend_kernel(T* __restrict__ h, int ld_h, const T* __restrict__ z, const T* __restrict__ q, int64_t rows, int c) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c;
+        const int ch = (int)(i - r * c);
+        const float zz = to_f32(z[i]), hh = to_f32(h[r * ld_h + ch]), qq = to_f32(q[i]);
+        h[r * ld_h + ch] = from_f32<T>((1.0f - zz) * hh + zz * qq);
+    }
+}
+
+// coords[b, 0, y, x] = (x + flow[b,0,y,x], y + flow[b,1,y,x]): coords1 of raft.py:58-66,121 as the lookup wants them
+__global__ void __launch_bounds__(256)
+coords_from_flow_kernel(float* __restrict__ coords, const float* __restrict__ flow, int n, int h, int w) {
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / hw);
+        const int64_t rem = i - (int64_t)b * hw;
+        const int y = (int)(rem / w), x = (int)(rem - (int64_t)y * w);
+        coords[i * 2 + 0] = (float)x + flow[((int64_t)b * 2 + 0) * hw + rem];
+        coords[i * 2 + 1] = (float)y + flow[((int64_t)b * 2 + 1) * hw + rem];
+    }
+}
+
+// RAFT.upsample_flow (raft.py:72-84): softmax over the 9 neighbours of mask (n, 9*64, h, w), convex combination of
+// the 3x3 neighbourhood of 8 * flow (zero outside), pixel shuffle to (n, 2, 8h, 8w).  One lane per fine pixel.
+__global__ void __launch_bounds__(256)
+convex_upsample_kernel(float* __restrict__ out, const float* __restrict__ flow, const float* __restrict__ mask,
+                       int n, int h, int w) {
+    const int64_t hw = (int64_t)h * w;
+    const int H8 = 8 * h, W8 = 8 * w;
+    const int64_t total = (int64_t)n * H8 * W8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / ((int64_t)H8 * W8));
+        const int64_t rem = i - (int64_t)b * H8 * W8;
+        const int Y = (int)(rem / W8), X = (int)(rem - (int64_t)Y * W8);
+        const int y = Y >> 3, ii = Y & 7, x = X >> 3, jj = X & 7;
+        const float* mp = mask + ((int64_t)b * 576 + ii * 8 + jj) * hw + (int64_t)y * w + x;
+        float m[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            m[k] = mp[(int64_t)k * 64 * hw];
+            mx = fmaxf(mx, m[k]);
+        }
+        float den = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            m[k] = expf(m[k] - mx);
+            den += m[k];
+        }
+        float u0 = 0.0f, u1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+                const float wk = m[k] / den;
+                const int64_t o = (int64_t)yy * w + xx;
+                u0 += wk * (8.0f * flow[((int64_t)b * 2 + 0) * hw + o]);
+                u1 += wk * (8.0f * flow[((int64_t)b * 2 + 1) * hw + o]);
+            }
+        }
+        out[((int64_t)b * 2 + 0) * H8 * W8 + rem] = u0;
+        out[((int64_t)b * 2 + 1) * H8 * W8 + rem] = u1;
+    }
+}
+
 }  // namespace
 
 extern "C" int vt_flow_warp(float* out, float* mask, const float* x, const float* flo, int n, int c, int h, int w,
@@ -149,4 +234,59 @@ extern "C" int vt_parsing_fuse(float* fused, const float* frames, const float* c
     VT_LAUNCH(parsing_fuse_kernel, dim3((unsigned)blocks), dim3(256), stream, fused, frames, center, parsing, flow, wt,
               wn, center_index, cp, h, w, 1.0f / (2.0f * sigma * sigma));
     return vt_check_launch("vt_parsing_fuse");
+}
+
+extern "C" int vt_eltwise2(void* out, int ld_out, const void* a, int ld_a, const void* b, int ld_b, int64_t rows,
+                           int c, int op, int dtype, vt_stream stream) {
+    VT_REQUIRE(out && a && b, "vt_eltwise2: null tensor");
+    VT_REQUIRE(rows > 0 && c > 0 && ld_out >= c && ld_a >= c && ld_b >= c && op >= 0 && op <= 2, "vt_eltwise2: bad arguments");
+    int64_t blocks = (rows * c + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == VT_F32) {
+        auto k = eltwise2_kernel<float>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (float*)out, ld_out, (const float*)a, ld_a, (const float*)b, ld_b, rows, c, op);
+    } else if (dtype == VT_BF16) {
+        auto k = eltwise2_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (bf16_t*)out, ld_out, (const bf16_t*)a, ld_a, (const bf16_t*)b, ld_b, rows, c, op);
+    } else {
+        vt_set_error("vt_eltwise2: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_eltwise2");
+}
+
+extern "C" int vt_gru_blend(void* h, int ld_h, const void* z, const void* q, int64_t rows, int c, int dtype,
+                            vt_stream stream) {
+    VT_REQUIRE(h && z && q, "vt_gru_blend: null tensor");
+    VT_REQUIRE(rows > 0 && c > 0 && ld_h >= c, "vt_gru_blend: bad sizes");
+    int64_t blocks = (rows * c + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == VT_F32) {
+        auto k = gru_blend_kernel<float>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (float*)h, ld_h, (const float*)z, (const float*)q, rows, c);
+    } else if (dtype == VT_BF16) {
+        auto k = gru_blend_kernel<bf16_t>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (bf16_t*)h, ld_h, (const bf16_t*)z, (const bf16_t*)q, rows, c);
+    } else {
+        vt_set_error("vt_gru_blend: dtype");
+        return VT_ERR_UNSUPPORTED;
+    }
+    return vt_check_launch("vt_gru_blend");
+}
+
+extern "C" int vt_coords_from_flow(float* coords, const float* flow, int n, int h, int w, vt_stream stream) {
+    VT_REQUIRE(coords && flow && n > 0 && h > 0 && w > 0, "vt_coords_from_flow: bad arguments");
+    int64_t blocks = ((int64_t)n * h * w + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    VT_LAUNCH(coords_from_flow_kernel, dim3((unsigned)blocks), dim3(256), stream, coords, flow, n, h, w);
+    return vt_check_launch("vt_coords_from_flow");
+}
+
+extern "C" int vt_convex_upsample(float* out, const float* flow, const float* mask, int n, int h, int w,
+                                  vt_stream stream) {
+    VT_REQUIRE(out && flow && mask && n > 0 && h > 0 && w > 0, "vt_convex_upsample: bad arguments");
+    int64_t blocks = ((int64_t)n * h * w * 64 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    VT_LAUNCH(convex_upsample_kernel, dim3((unsigned)blocks), dim3(256), stream, out, flow, mask, n, h, w);
+    return vt_check_launch("vt_convex_upsample");
 }

@@ -74,6 +74,11 @@ def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
         if ".res_layer." in key:
             return randn(0.5 * math.sqrt(2.0 / fan_in))
 
+    # --- RAFT (model/raft/core): eval-mode BatchNorm affine of the context encoder ~ (1, 0) ---
+    if key.startswith(("cnet.", "fnet.")) and len(shape) == 1 and leaf in ("weight", "bias") and \
+            ("norm" in key or "downsample.1" in key):
+        return (1.0 + randn(0.1)) if leaf == "weight" else randn(0.1)
+
     # --- BiSeNet face parsing (model/bisenet): eval-mode BatchNorm affine ~ (1, 0) -----------
     if key.startswith(("cp.", "ffm.", "conv_out")) and len(shape) == 1 and leaf in ("weight", "bias"):
         return (1.0 + randn(0.1)) if leaf == "weight" else randn(0.1)
