@@ -28,6 +28,17 @@ def test_state_dict_schema_matches_reference():
         RAFT(argparse.Namespace(small=True))
 
 
+def test_oracle_pinned_to_reference_raft():
+    """oracle/raft_oracle.py:raft_forward against the reference's RAFT class on a crop small enough for the pure-numpy
+    correlation loop (the reference needs >= 128x128: four pyramid levels of at least 2x2)."""
+    from oracle import raft_oracle as R
+    d, _ = load_golden("raft_net.npz")
+    sd = synth.to_numpy_sd(synth.synth_state_dict(load_keys("raft"), 0))
+    lo, up = R.raft_forward(sd, d["b__image1"][:1].astype(np.float32), d["b__image2"][:1].astype(np.float32),
+                            int(d["b__cfg"][0]))
+    assert rel_err(lo, d["b__flow_low"][:1]) < TOL and rel_err(up, d["b__flow_up"][:1]) < TOL
+
+
 def test_first_iteration_stage_by_stage(dev):
     d, _ = load_golden("raft_net.npz")
     eng = RaftEngine(synth.synth_state_dict(load_keys("raft"), 0), torch.float32, dev)
@@ -64,6 +75,37 @@ def test_module_surface_like_smooth_parsing_map(dev):
         assert len(preds) == iters and torch.equal(preds[-1], flow_up)
     with pytest.raises(_lib.VtError, match="multiples of 8"):
         m(im1[:, :, :-3], im2[:, :, :-3])
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="reference checkout not mounted")
+def test_reference_construction_lines_run_on_the_mirror(tmp_path):
+    """smooth_parsing_map.py:91-102 executed verbatim (read from the reference at run time) with
+    `from model.raft.core.raft import RAFT` resolved by the mirror package: argparse -> RAFT(args) ->
+    nn.DataParallel -> load_state_dict of a `module.`-prefixed checkpoint -> .module -> .to(device) -> .eval()."""
+    import os
+    import sys
+    import textwrap
+    from emu import build_emu
+    _lib.use_library(build_emu.build())
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert sys.path[0] == repo or repo in sys.path
+    from model.raft.core.raft import RAFT as MirrorRAFT
+    assert MirrorRAFT is RAFT
+    sd = synth.synth_state_dict(load_keys("raft"), 0)
+    ck = tmp_path / "raft-things.pth"
+    torch.save({"module." + k: v for k, v in sd.items()}, ck)
+    src = "/root/reference/smooth_parsing_map.py"
+    with open(src) as f:
+        code = textwrap.dedent("".join(f.readlines()[90:102]))
+    ns = {"torch": torch, "argparse": argparse, "RAFT": MirrorRAFT, "device": "cpu",
+          "args": argparse.Namespace(raft_path=str(ck))}
+    exec(compile(code, src, "exec"), ns)
+    m = ns["raft_model"]
+    assert isinstance(m, RAFT) and not m.training
+    d, _ = load_golden("raft_net.npz")
+    im1, im2 = (torch.from_numpy(d[k][:1].astype(np.float32)) for k in ("b__image1", "b__image2"))
+    flow_low, flow_up = m(im1, im2, iters=int(d["b__cfg"][0]), test_mode=True)
+    assert rel_err(flow_up.numpy(), d["b__flow_up"][:1]) < TOL
 
 
 def test_asymmetric_padding_convs(dev):
