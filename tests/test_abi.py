@@ -87,3 +87,22 @@ def test_vtoonify_signature_and_state_dict_schema():
         want = load_keys(tag)
         got = {k: tuple(v.shape) for k, v in VToonify(backbone=bb).state_dict().items()}
         assert len(want) == n and got == want
+
+
+def test_hot_kernels_do_not_spill():
+    """Registers / scratch of every kernel of the built gfx950 objects (tools/kernel_resources.py).  A spill in an
+    unrolled epilogue is invisible in the source: two extra activation branches in conv_finish put 272 bytes of scratch
+    per lane into the 128-channel tile kernels and cost the 256x128 instance 35 % (round 2).  Only the kernels that are
+    deliberately capped at 256 registers (`__launch_bounds__(T, 2)`) may keep a few cold
+    values in scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from vtoonify_amd import build
+    build.build(verbose=False)
+    import kernel_resources
+    table = kernel_resources.kernel_table()
+    assert len(table) > 100
+    capped = ("conv3x3_c64_kernel", "conv_upblur_kernel")
+    bad = {k: v["scratch"] for k, v in table.items()
+           if v["scratch"] > (128 if any(c in k for c in capped) else 0)}
+    assert not bad, bad
