@@ -148,6 +148,8 @@ struct LinearTable {
 // and dotted with every input row of the item, RB rows at a time -- the style MLP applies the same 512x512
 // matrix to 18 latent rows, and one wave per (row, output) re-read it 18 times in 4-byte pieces (35 us for the
 // first dependency level of a frame; the 12 MB of fp32 weights are 2-3 us of HBM).
+// (Measured and dropped, round 2: FOUR output columns per wavefront -- a quarter of the waves, four weight rows in
+//  flight per lane -- is 2x slower: 52 + 45 + 20 us against 18 + 17 + 25 us for the three launches of a frame.)
 __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) {
     constexpr int RB = 6;
     const int lane = threadIdx.x & 63;
