@@ -894,3 +894,55 @@ def test_conv_transpose_blur_kernel(dev, dtype):
         K.conv2d(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpp, cout=cout, kh=3, kw=3, pad=1,
                  phases=4, bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out2, ld_out=cout, dtype=K.dt_code(dtype))
         assert rel_err(y, out2.float().cpu().permute(0, 3, 1, 2).numpy()) < (t if dtype == torch.float32 else 2.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fusion_gate_equals_three_launches(dev, dtype):
+    """vt_fusion_gate (csrc/fusion_glue.hip): Fusion.forward's gate (vtoonify.py:122-128) -- AdaIN affine of
+    cat[f_G, |f_G - f_E|], the 2C -> 1 mask conv with relu + tanh, the [skip | 0 | f_E * m] operand -- against
+    vt_affine_apply -> vt_conv2d -> vt_fusion_pack and against the torch formula; tile edges, batch 2."""
+    import ctypes as C
+    from vtoonify_amd import _lib
+    lib = _lib.lib()
+    g = np.random.default_rng(17)
+    kstep = 16 if dtype == torch.float32 else 32
+    for (N, c, H, W) in ((1, 2 * kstep, 8, 8), (2, 3 * kstep, 11, 13), (1, 4 * kstep, 5, 20)):
+        fg = g.standard_normal((N, c, H, W)).astype(np.float32)
+        fe = g.standard_normal((N, c, H, W)).astype(np.float32)
+        w = (g.standard_normal((1, 2 * c, 3, 3)) / math.sqrt(18 * c)).astype(np.float32)
+        bias = g.standard_normal(1).astype(np.float32) * 0.1
+        sc = (1 + 0.3 * g.standard_normal((N, 2 * c))).astype(np.float32)
+        sh = (0.3 * g.standard_normal((N, 2 * c))).astype(np.float32)
+        skip = g.standard_normal((N, 3, H, W)).astype(np.float32)
+        fgt, fet = K.nchw_to_nhwc(T(fg, dev), dtype), K.nchw_to_nhwc(T(fe, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        sct, sht, skt, bt = T(sc, dev), T(sh, dev), T(skip, dev), T(bias, dev)
+        hdr = 64
+        mask = torch.zeros((N, 1, H, W), device=dev)
+        fem = torch.zeros((N, H, W, c + hdr), dtype=dtype, device=dev)
+        _lib.check(lib.vt_fusion_gate(C.c_void_p(mask.data_ptr()), C.c_void_p(fem.data_ptr()), c + hdr,
+                                      C.c_void_p(fgt.data_ptr()), c, C.c_void_p(fet.data_ptr()), c,
+                                      C.c_void_p(sct.data_ptr()), C.c_void_p(sht.data_ptr()), C.c_void_p(wp.data_ptr()),
+                                      C.c_void_p(bt.data_ptr()), C.c_void_p(skt.data_ptr()), N, H, W, c, K.dt_code(dtype),
+                                      K._stream(mask)), "vt_fusion_gate")
+        # the three-launch path
+        nrm = torch.zeros((N, H, W, 2 * c), dtype=dtype, device=dev)
+        K.affine_apply(nrm, 2 * c, fgt, c, sct, sht, N, H * W, c, K.dt_code(dtype), other=fet, ld_other=c)
+        mask3 = torch.zeros((N, 1, H, W), device=dev)
+        K.conv2d(src0=nrm, c0=2 * c, ld0=2 * c, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=1, kh=3, kw=3, pad=1,
+                 bias=bt, act=K.ACT_RELU_TANH, out=mask3, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32,
+                 dtype=K.dt_code(dtype))
+        fem3 = torch.zeros_like(fem)
+        K.fusion_pack(fem3, c + hdr, fet, c, mask3, skt, N, H * W, c, K.dt_code(dtype))
+        # torch formula on the operands as the kernels see them
+        fgq, feq = fgt.float().cpu().permute(0, 3, 1, 2), fet.float().cpu().permute(0, 3, 1, 2)
+        x = torch.cat([fgq, (fgq - feq).abs()], 1) * torch.from_numpy(sc)[:, :, None, None] + torch.from_numpy(sh)[:, :, None, None]
+        wq = wp.float().cpu().view(1, 3, 3, 2 * c).permute(0, 3, 1, 2)
+        mref = torch.tanh(torch.relu(torch.nn.functional.conv2d(x, wq, torch.from_numpy(bias), padding=1)))
+        tol = 1e-5 if dtype == torch.float32 else 2e-2     # bf16: W * s rounded instead of s * x + t
+        assert float((mask.cpu() - mref).abs().max()) < tol, (N, c, H, W)
+        assert float((mask3.cpu() - mref).abs().max()) < tol
+        body = fem.float().cpu()[..., hdr:].permute(0, 3, 1, 2)
+        assert float((body - feq * mask.cpu()).abs().max()) < (1e-6 if dtype == torch.float32 else 3e-2)
+        assert torch.equal(fem[..., :hdr], fem3[..., :hdr])      # [skip | zeros]
+        assert float((fem.float() - fem3.float()).abs().max()) < (1e-5 if dtype == torch.float32 else 6e-2)

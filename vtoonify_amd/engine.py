@@ -94,6 +94,8 @@ class VToonifyEngine:
         self.fork_style = os.environ.get("VT_STYLE_FORK", "0") != "0"
         # RGB-skip path (fusion_skip conv, skip up-sampling, encoder ToRGB) on a third stream / branch
         self.fork_thin = os.environ.get("VT_THIN_FORK", "0") != "0"
+        # Fusion gate (AdaIN affine + mask conv + pack) as one launch; VT_FUSE_GATE=0: three launches (A/B)
+        self.fuse_gate = os.environ.get("VT_FUSE_GATE", "1") != "0"
         # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
         # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
         self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
@@ -568,20 +570,34 @@ class VToonifyEngine:
                                  0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
                                 {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
                                  "bytes": 2 * B * hw * co * self.esz}))
-                    nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                    ops.append((lib.vt_affine_apply,
+                    mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
+                    if self.fuse_gate:
+                        # AdaIN affine + |f_G - f_E| + mask conv + [skip | f_E * m] pack in ONE launch (vt_fusion_gate)
+                        ops.append((lib.vt_fusion_gate,
+                                    (C.c_void_p(mask.data_ptr()), C.c_void_p(fem.data_ptr()), co + FEM_HDR,
+                                     C.c_void_p(out.data_ptr()), co, C.c_void_p(f_e.data_ptr()), co,
+                                     C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
+                                     C.c_void_p(self.w[f"fusion_out.{lvl}.conv2"].data_ptr()),
+                                     C.c_void_p(sd[f"fusion_out.{lvl}.conv2.bias"].data_ptr()),
+                                     C.c_void_p(skip.data_ptr()), B, h, w, co, dt),
+                                    {"name": "fusion_gate", "kernel": "fusion_gate", "flops": 2 * B * hw * 2 * co * 9,
+                                     "join": True, "bytes": B * hw * (2 * co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
+                        plan.masks.append(mask)
+                    nrm = None if self.fuse_gate else self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                    if not self.fuse_gate:
+                      ops.append((lib.vt_affine_apply,
                                 (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
                                  C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
                                  B, hw, co, dt),
                                 {"name": "affine", "kernel": "affine_apply", "flops": 0,
                                  "bytes": 4 * B * hw * co * self.esz}))
-                    mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
-                    self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
-                                  weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
-                                  bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
-                                  out_layout=OUT_NCHW, out_dtype=K.VT_F32)
-                    plan.masks.append(mask)
-                ops.append((lib.vt_fusion_pack,
+                      self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
+                                    weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
+                                    bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
+                                    out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                      plan.masks.append(mask)
+                if not (self.dual and self.fuse_gate):
+                  ops.append((lib.vt_fusion_pack,
                             (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
                              C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
                              B, hw, co, dt),
