@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KSTEP = 4 * VEC;
     __shared__ __attribute__((aligned(16))) float dpart[FG_NW][FG_NF * 16][FG_DLD];
-    __shared__ float tpart[9][FG_NW * 64];
+    __shared__ float tpart[9][FG_NW];
     __shared__ float tsum[9];
     __shared__ float mtile[64];
 
@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     const float* sc = p.scale + (int64_t)img * C2;
     const float* sh = p.shift + (int64_t)img * C2;
 
-    // T[tap] = sum_c W[tap][c] * shift[c]: every thread a strided share of the 2C channels, tree through LDS
+    // T[tap] = sum_c W[tap][c] * shift[c]: every thread a strided share of the 2C channels, xor tree per wave, then
+    // the four wave sums in wave order
     {
         float part[9];
 #pragma unroll
@@ -106,7 +107,10 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
             for (int t = 0; t < 9; ++t) part[t] += to_f32(wg[(int64_t)t * C2 + ch]) * s;
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) tpart[t][tid] = part[t];
+        for (int t = 0; t < 9; ++t) {
+            const float ws = wave_sum(part[t]);
+            if (lane == 0) tpart[t][wave] = ws;
+        }
     }
 
     // this lane's patch pixel of every fragment -> pixel index (or -1), for both tensors
@@ -124,37 +128,50 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     for (int f = 0; f < FG_NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
     const u128 zero = u128{0u, 0u, 0u, 0u};
     const int nk = C2 / KSTEP;
-    for (int ks = wave; ks < nk; ks += FG_NW) {
-        const int kb = ks * KSTEP + q * VEC;       // first of this lane's VEC channels of cat[f_G, |f_G - f_E|]
-        const bool second = kb >= C;
-        const int kc = second ? kb - C : kb;       // channel in f_G / f_E
-        // weight fragment: row l15 = tap (rows 9..15 are zero), scaled by the AdaIN scale of its channels
-        u128 fw = zero;
-        if (l15 < 9) {
-            float wv[VEC];
-            unpack16<T>(ld128(wg + (int64_t)l15 * C2 + kb), wv);
+    constexpr int UNR = 2;   // K-steps whose loads are in flight together (one K-step per round trip measured 36-38 us
+                             // per launch at 16-64 workgroups: every step waited for its own 16-23 loads)
+    for (int k0 = wave; k0 < nk; k0 += FG_NW * UNR) {
+        u128 ra[UNR][FG_NF], rb[UNR][FG_NF], rw[UNR];
+        float rs[UNR][VEC];
+        bool second[UNR], livek[UNR];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) wv[k] *= sc[kb + k];
-            fw = pack16<T>(wv);
-        }
-        u128 fa[FG_NF];
+        for (int u = 0; u < UNR; ++u) {
+            const int ks = k0 + u * FG_NW;
+            livek[u] = ks < nk;
+            const int kb = (livek[u] ? ks : k0) * KSTEP + q * VEC;   // first of this lane's VEC channels of cat[f_G, |f_G - f_E|]
+            second[u] = kb >= C;
+            const int kc = second[u] ? kb - C : kb;                  // channel in f_G / f_E
+            rw[u] = (livek[u] && l15 < 9) ? ld128(wg + (int64_t)l15 * C2 + kb) : zero;   // row l15 = tap; rows 9..15 zero
 #pragma unroll
-        for (int f = 0; f < FG_NF; ++f) {
-            if (pix[f] < 0) {
-                fa[f] = zero;
-            } else if (!second) {
-                fa[f] = ld128(fg + pix[f] * p.ld_g + kc);
-            } else {
-                float a[VEC], b[VEC];
-                unpack16<T>(ld128(fg + pix[f] * p.ld_g + kc), a);
-                unpack16<T>(ld128(fe + pix[f] * p.ld_e + kc), b);
+            for (int k = 0; k < VEC; k += 4) unpack16<float>(ld128(sc + kb + k), rs[u] + k);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) a[k] = fabsf(a[k] - b[k]);
-                fa[f] = pack16<T>(a);
+            for (int f = 0; f < FG_NF; ++f) {
+                const bool on = livek[u] && pix[f] >= 0;
+                ra[u][f] = on ? ld128(fg + pix[f] * p.ld_g + kc) : zero;
+                rb[u][f] = (on && second[u]) ? ld128(fe + pix[f] * p.ld_e + kc) : zero;
             }
         }
 #pragma unroll
-        for (int f = 0; f < FG_NF; ++f) Mma1<T>::run(acc[f], fw, fa[f]);
+        for (int u = 0; u < UNR; ++u) {
+            float wv[VEC];
+            unpack16<T>(rw[u], wv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) wv[k] *= rs[u][k];          // the AdaIN scale of the fragment's channels
+            const u128 fw = pack16<T>(wv);
+#pragma unroll
+            for (int f = 0; f < FG_NF; ++f) {
+                u128 fa = ra[u][f];
+                if (second[u]) {
+                    float a[VEC], b[VEC];
+                    unpack16<T>(ra[u][f], a);
+                    unpack16<T>(rb[u][f], b);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) a[k] = fabsf(a[k] - b[k]);
+                    fa = pack16<T>(a);
+                }
+                Mma1<T>::run(acc[f], fw, fa);
+            }
+        }
     }
 #pragma unroll
     for (int f = 0; f < FG_NF; ++f) {
@@ -164,7 +181,8 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     __syncthreads();
     if (tid < 9) {   // finish T[tap] in thread order (deterministic)
         float s = 0.0f;
-        for (int i = 0; i < FG_NW * 64; ++i) s += tpart[tid][i];
+#pragma unroll
+        for (int i = 0; i < FG_NW; ++i) s += tpart[tid][i];
         tsum[tid] = s;
     }
     __syncthreads();
@@ -195,27 +213,49 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     const int hv = hdr / VEC, per_px = hv + C / VEC;
     T* fem = (T*)p.fem;
     const int64_t hw = (int64_t)p.h * p.w;
-    for (int i = tid; i < 64 * per_px; i += FG_NW * 64) {
-        const int opix = i / per_px, v = i - opix * per_px;
-        const int py = opix / FG_TW, px = opix - py * FG_TW;
-        if (y0 + py >= p.h || x0 + px >= p.w) continue;
-        const int64_t pg = (int64_t)(img * p.h + y0 + py) * p.w + x0 + px;
-        float f[VEC];
-        if (v < hv) {
-            const int64_t pl = (int64_t)(y0 + py) * p.w + x0 + px;
+    constexpr int PB = 6;    // vectors per thread per round trip (a load -> store chain per vector serialised 18 of them)
+    for (int i0 = tid; i0 < 64 * per_px; i0 += FG_NW * 64 * PB) {
+        u128 val[PB];
+        int64_t dst[PB];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int ch = v * VEC + k;
-                f[k] = (ch < 3) ? p.skip[((int64_t)img * 3 + ch) * hw + pl] : 0.0f;
+        for (int b = 0; b < PB; ++b) {
+            const int i = i0 + b * FG_NW * 64;
+            dst[b] = -1;
+            val[b] = zero;
+            if (i >= 64 * per_px) continue;
+            const int opix = i / per_px, v = i - opix * per_px;
+            const int py = opix / FG_TW, px = opix - py * FG_TW;
+            if (y0 + py >= p.h || x0 + px >= p.w) continue;
+            const int64_t pg = (int64_t)(img * p.h + y0 + py) * p.w + x0 + px;
+            if (v < hv) {
+                const int64_t pl = (int64_t)(y0 + py) * p.w + x0 + px;
+                float f[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const int ch = v * VEC + k;
+                    f[k] = (ch < 3) ? p.skip[((int64_t)img * 3 + ch) * hw + pl] : 0.0f;
+                }
+                val[b] = pack16<T>(f);
+                dst[b] = pg * p.ld_fem + v * VEC;
+            } else {
+                val[b] = ld128(fe + pg * p.ld_e + (v - hv) * VEC);
+                dst[b] = pg * p.ld_fem + hdr + (v - hv) * VEC;
             }
-            st128(fem + pg * p.ld_fem + v * VEC, pack16<T>(f));
-        } else {
-            const int cv = v - hv;
-            const float m = mtile[opix];
-            unpack16<T>(ld128(fe + pg * p.ld_e + cv * VEC), f);
+        }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) f[k] *= m;
-            st128(fem + pg * p.ld_fem + hdr + cv * VEC, pack16<T>(f));
+        for (int b = 0; b < PB; ++b) {
+            if (dst[b] < 0) continue;
+            const int i = i0 + b * FG_NW * 64;
+            const int opix = i / per_px, v = i - opix * per_px;
+            if (v >= hv) {
+                float f[VEC];
+                unpack16<T>(val[b], f);
+                const float m = mtile[opix];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) f[k] *= m;
+                val[b] = pack16<T>(f);
+            }
+            st128(fem + dst[b], val[b]);
         }
     }
 }
