@@ -24,7 +24,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #endif
 
-constexpr int FG_TW = 8, FG_NW = 4, FG_PW = 10, FG_NPIX = 100, FG_NF = 7, FG_DLD = 20;
+constexpr int FG_TW = 8, FG_PW = 10, FG_NPIX = 100, FG_NF = 7, FG_DLD = 20;
+// 16 wavefronts per workgroup = 4 K-slices x 4 pixel-fragment groups (2, 2, 2, 1 fragments): at 32x32 / 64x64 pixels
+// there are only 16 / 64 tiles, so the latency chain INSIDE a workgroup is the launch time -- with 4 waves (8 K-steps and
+// 18 pack vectors per lane in sequence) the fused kernel took 32 us where the three separate launches took 21
+constexpr int FG_KG = 4, FG_PG = 4, FG_FPG = 2, FG_NW = FG_KG * FG_PG;
 
 struct FusionGateArgs {
     float* mask;
@@ -75,7 +79,7 @@ template <typename T>
 __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGateArgs p) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KSTEP = 4 * VEC;
-    __shared__ __attribute__((aligned(16))) float dpart[FG_NW][FG_NF * 16][FG_DLD];
+    __shared__ __attribute__((aligned(16))) float dpart[FG_KG][FG_NF * 16][FG_DLD];
     __shared__ float tpart[9][FG_NW];
     __shared__ float tsum[9];
     __shared__ float mtile[64];
@@ -83,6 +87,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = vt_uniform(tid >> 6) & (FG_NW - 1);
+    const int kg = wave & (FG_KG - 1), pgp = wave >> 2;      // K-slice, pixel-fragment group
     const int q = lane >> 4, l15 = lane & 15;
     const int tiles_x = (p.w + FG_TW - 1) / FG_TW, tiles_y = (p.h + FG_TW - 1) / FG_TW;
     const int img = blockIdx.x / (tiles_x * tiles_y);
@@ -114,29 +119,28 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     }
 
     // this lane's patch pixel of every fragment -> pixel index (or -1), for both tensors
-    int64_t pix[FG_NF];
+    int64_t pix[FG_FPG];
 #pragma unroll
-    for (int f = 0; f < FG_NF; ++f) {
-        const int pp = f * 16 + l15;
+    for (int f = 0; f < FG_FPG; ++f) {
+        const int pp = (pgp * FG_FPG + f) * 16 + l15;   // (fragment 7 of the last group does not exist: pp >= 100)
         const int py = pp / FG_PW, px = pp - py * FG_PW;
         const int iy = y0 + py - 1, ix = x0 + px - 1;
         const bool in = pp < FG_NPIX && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
         pix[f] = in ? (int64_t)(img * p.h + iy) * p.w + ix : -1;
     }
-    f32x4 acc[FG_NF];
+    f32x4 acc[FG_FPG];
 #pragma unroll
-    for (int f = 0; f < FG_NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < FG_FPG; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
     const u128 zero = u128{0u, 0u, 0u, 0u};
     const int nk = C2 / KSTEP;
-    constexpr int UNR = 2;   // K-steps whose loads are in flight together (one K-step per round trip measured 36-38 us
-                             // per launch at 16-64 workgroups: every step waited for its own 16-23 loads)
-    for (int k0 = wave; k0 < nk; k0 += FG_NW * UNR) {
-        u128 ra[UNR][FG_NF], rb[UNR][FG_NF], rw[UNR];
+    constexpr int UNR = 3;   // K-steps whose loads are in flight together (4: 72 bytes of scratch under the 128-register cap)
+    for (int k0 = kg; k0 < nk; k0 += FG_KG * UNR) {
+        u128 ra[UNR][FG_FPG], rb[UNR][FG_FPG], rw[UNR];
         float rs[UNR][VEC];
         bool second[UNR], livek[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int ks = k0 + u * FG_NW;
+            const int ks = k0 + u * FG_KG;
             livek[u] = ks < nk;
             const int kb = (livek[u] ? ks : k0) * KSTEP + q * VEC;   // first of this lane's VEC channels of cat[f_G, |f_G - f_E|]
             second[u] = kb >= C;
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
 #pragma unroll
             for (int k = 0; k < VEC; k += 4) unpack16<float>(ld128(sc + kb + k), rs[u] + k);
 #pragma unroll
-            for (int f = 0; f < FG_NF; ++f) {
+            for (int f = 0; f < FG_FPG; ++f) {
                 const bool on = livek[u] && pix[f] >= 0;
                 ra[u][f] = on ? ld128(fg + pix[f] * p.ld_g + kc) : zero;
                 rb[u][f] = (on && second[u]) ? ld128(fe + pix[f] * p.ld_e + kc) : zero;
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
             for (int k = 0; k < VEC; ++k) wv[k] *= rs[u][k];          // the AdaIN scale of the fragment's channels
             const u128 fw = pack16<T>(wv);
 #pragma unroll
-            for (int f = 0; f < FG_NF; ++f) {
+            for (int f = 0; f < FG_FPG; ++f) {
                 u128 fa = ra[u][f];
                 if (second[u]) {
                     float a[VEC], b[VEC];
@@ -174,9 +178,12 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
         }
     }
 #pragma unroll
-    for (int f = 0; f < FG_NF; ++f) {
-        float v4[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
-        st128(&dpart[wave][f * 16 + l15][q * 4], pack16<float>(v4));
+    for (int f = 0; f < FG_FPG; ++f) {
+        const int fr = pgp * FG_FPG + f;
+        if (fr < FG_NF) {
+            float v4[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+            st128(&dpart[kg][fr * 16 + l15][q * 4], pack16<float>(v4));
+        }
     }
     __syncthreads();
     if (tid < 9) {   // finish T[tap] in thread order (deterministic)
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
             const int iy = gy + ky - 1, ix = gx + kx - 1;
             float t = 0.0f;
 #pragma unroll
-            for (int w = 0; w < FG_NW; ++w) t += dpart[w][pp][tap];
+            for (int w = 0; w < FG_KG; ++w) t += dpart[w][pp][tap];
             if ((unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w) t += tsum[tap];
             s += t;
         }
@@ -213,7 +220,7 @@ __global__ void __launch_bounds__(FG_NW * 64) fusion_gate_kernel(const FusionGat
     const int hv = hdr / VEC, per_px = hv + C / VEC;
     T* fem = (T*)p.fem;
     const int64_t hw = (int64_t)p.h * p.w;
-    constexpr int PB = 6;    // vectors per thread per round trip (a load -> store chain per vector serialised 18 of them)
+    constexpr int PB = 5;    // vectors per thread per round trip (a load -> store chain per vector serialised them)
     for (int i0 = tid; i0 < 64 * per_px; i0 += FG_NW * 64 * PB) {
         u128 val[PB];
         int64_t dst[PB];
