@@ -94,8 +94,11 @@ class VToonifyEngine:
         self.fork_style = os.environ.get("VT_STYLE_FORK", "0") != "0"
         # RGB-skip path (fusion_skip conv, skip up-sampling, encoder ToRGB) on a third stream / branch
         self.fork_thin = os.environ.get("VT_THIN_FORK", "0") != "0"
-        # Fusion gate (AdaIN affine + mask conv + pack) as one launch; VT_FUSE_GATE=0: three launches (A/B)
-        self.fuse_gate = os.environ.get("VT_FUSE_GATE", "1") != "0"
+        # Fusion gate (AdaIN affine + mask conv + pack) as ONE launch (vt_fusion_gate): VT_FUSE_GATE=1.  Off by default:
+        # measured 24 + 25 + 18 + 42 us against 21 + 24 + 25 + 36 us for the three launches (same box; frame 875 -> 862):
+        # with 16-64 tiles per level the chain load -> MFMA -> stencil -> pack inside ONE workgroup is longer than
+        # three short kernels that each spread over hundreds of workgroups
+        self.fuse_gate = os.environ.get("VT_FUSE_GATE", "0") != "0"
         # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
         # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
         self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
