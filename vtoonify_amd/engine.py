@@ -585,27 +585,26 @@ class VToonifyEngine:
                                      C.c_void_p(skip.data_ptr()), B, h, w, co, dt),
                                     {"name": "fusion_gate", "kernel": "fusion_gate", "flops": 2 * B * hw * 2 * co * 9,
                                      "join": True, "bytes": B * hw * (2 * co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
-                        plan.masks.append(mask)
-                    nrm = None if self.fuse_gate else self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                    if not self.fuse_gate:
-                      ops.append((lib.vt_affine_apply,
-                                (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
-                                 C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
-                                 B, hw, co, dt),
-                                {"name": "affine", "kernel": "affine_apply", "flops": 0,
-                                 "bytes": 4 * B * hw * co * self.esz}))
-                      self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
-                                    weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
-                                    bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
-                                    out_layout=OUT_NCHW, out_dtype=K.VT_F32)
-                      plan.masks.append(mask)
+                    else:
+                        nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                        ops.append((lib.vt_affine_apply,
+                                    (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                     C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
+                                     B, hw, co, dt),
+                                    {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                     "bytes": 4 * B * hw * co * self.esz}))
+                        self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
+                                      weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
+                                      bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
+                                      out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                    plan.masks.append(mask)
                 if not (self.dual and self.fuse_gate):
-                  ops.append((lib.vt_fusion_pack,
-                            (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
-                             C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
-                             B, hw, co, dt),
-                            {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0, "join": True,
-                             "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
+                    ops.append((lib.vt_fusion_pack,
+                                (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
+                                 C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
+                                 B, hw, co, dt),
+                                {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0, "join": True,
+                                 "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
                 self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + FEM_HDR * self.esz, c1=co,
