@@ -96,7 +96,7 @@ def test_reference_style_transfer_lines_run_on_the_mirror(tmp_path, backbone):
 
 
 def test_mirror_package_re_exports_without_the_reference():
-    """The mirror alone (no reference on the path): the five import targets resolve to vtoonify_amd."""
+    """The mirror alone (no reference on the path): the six import targets resolve to vtoonify_amd."""
     code = textwrap.dedent(f"""
         import sys
         sys.path.insert(0, {REPO!r})
@@ -105,7 +105,9 @@ def test_mirror_package_re_exports_without_the_reference():
         from model.stylegan.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix
         from model.stylegan.op.conv2d_gradfix import conv2d, conv_transpose2d, no_weight_gradients
         from model.encoder.encoders.psp_encoders import GradualStyleEncoder
-        import vtoonify_amd.op, vtoonify_amd.vtoonify, vtoonify_amd.psp, vtoonify_amd.bisenet
+        from model.raft.core.raft import RAFT                     # smooth_parsing_map.py:12
+        import vtoonify_amd.op, vtoonify_amd.vtoonify, vtoonify_amd.psp, vtoonify_amd.bisenet, vtoonify_amd.raft
+        assert RAFT is vtoonify_amd.raft.RAFT
         assert VToonify is vtoonify_amd.vtoonify.VToonify and BiSeNet is vtoonify_amd.bisenet.BiSeNet
         assert GradualStyleEncoder is vtoonify_amd.psp.GradualStyleEncoder
         assert conv2d_gradfix is vtoonify_amd.op.conv2d_gradfix and conv2d is conv2d_gradfix.conv2d
