@@ -64,7 +64,8 @@ def pmc_traffic(kernel_class: str):
     import re
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
+    src = "profiles/" + os.path.basename(files[-1]) + " (committed rocprofv3 --pmc pass of this command, not this run)"
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
     m = re.match(r"(\w+)<(\w+),(\d+)x(\d+)>", kernel_class)
@@ -82,8 +83,117 @@ def pmc_traffic(kernel_class: str):
         hit = [v for k, v in table.items() if k.startswith(lead)]
     n = sum(v["launches_sampled"] for v in hit)
     if not n:
-        return None
-    return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hit) / n
+        return None, None
+    return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hit) / n, src
+
+
+
+def op_surface(dev, iters=10):
+    """Stand-alone rates of the two operators the reference implements as CUDA kernels -- upfirdn2d
+    (model/stylegan/op/upfirdn2d_kernel.cu:107-207) and fused_leaky_relu (fused_bias_act_kernel.cu:18-65) --
+    through the drop-in surface (vtoonify_amd.op) at the tensor sizes one VToonify-D frame at 22x256x256 gives them
+    (SURVEY.md 8a rows a13/a14), bf16 and fp32: ALGORITHMIC bytes (input + output once) / GPU time, `iters` calls per
+    hipGraph replay (the same protocol as tools/op_bench.py)."""
+    from vtoonify_amd import synth
+    from vtoonify_amd.op import fused_leaky_relu, upfirdn2d
+
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / iters
+            best = us if best is None else min(best, us)
+        return best
+
+    k = synth.fir_kernel_2d().to(dev)
+    rows = []
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        esz = 2 if dt == torch.bfloat16 else 4
+        for c, s in ((512, 65), (128, 257), (32, 1025)):     # Blur after the transposed conv (model.py:74-90)
+            x = torch.randn(1, c, s, s, device=dev).to(dt)
+            us = timeit(lambda: upfirdn2d(x, k * 4, pad=(1, 1)))
+            rows.append((f"upfirdn2d blur ({c},{s},{s}) {name}", us, (x.numel() + c * (s - 1) ** 2) * esz))
+        x = torch.randn(1, 64, 512, 512, device=dev).to(dt)  # Downsample (model.py:53-71, smooth_parsing_map.py:108)
+        us = timeit(lambda: upfirdn2d(x, k, down=2, pad=(1, 1)))
+        rows.append((f"upfirdn2d down2 (64,512,512) {name}", us, (x.numel() + 64 * 256 * 256) * esz))
+        x = torch.randn(1, 32, 512, 512, device=dev).to(dt)  # Upsample (model.py:32-50) on a feature-sized tensor
+        us = timeit(lambda: upfirdn2d(x, k * 4, up=2, pad=(2, 1)))
+        rows.append((f"upfirdn2d up2 (32,512,512) {name}", us, (x.numel() + 32 * 1024 * 1024) * esz))
+        for c, s in ((512, 32), (128, 256), (32, 1024)):     # FusedLeakyReLU (op/fused_act.py:104-119)
+            x = torch.randn(1, c, s, s, device=dev).to(dt)
+            b = torch.randn(c, device=dev).to(dt)
+            us = timeit(lambda: fused_leaky_relu(x, b))
+            rows.append((f"fused_leaky_relu ({c},{s},{s}) {name}", us, (2 * x.numel() + c) * esz))
+    for s in (32, 512):                                       # Upsample of the fp32 RGB skip planes
+        x = torch.randn(1, 3, s, s, device=dev)
+        us = timeit(lambda: upfirdn2d(x, k * 4, up=2, pad=(2, 1)))
+        rows.append((f"upfirdn2d up2 (3,{s},{s}) fp32", us, (x.numel() + 12 * s * s) * 4))
+    return {"unit": "GB/s", "peak": PEAK_HBM_GBS, "protocol": f"{iters} calls per hipGraph replay, best of 3 replays",
+            "rows": [{"op": n, "us": round(us, 2), "gbs": round(nb / us / 1e3, 1),
+                      "frac": round(nb / us / 1e3 / PEAK_HBM_GBS, 4)} for n, us, nb in rows]}
+
+
+def kernel_table(eng, plan, dtype, iters, emu=False, want_ops=False):
+    """Per-kernel-class table of one frame (HIP events on the launch stream around every launch, engine.time_ops)
+    and the `roofline` object of the class with the largest share of GPU time."""
+    if emu:   # no HIP events on the host: one conv entry stands in for the table
+        per_op = [(next(info for _, info, _, _ in plan.convs), 1.0)]
+    else:
+        per_op = eng.time_ops(plan, iters=iters, with_style=True)
+    classes = {}
+    for info, ms in per_op:
+        c = classes.setdefault(info["kernel"], {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
+        c["ms"] += ms
+        c["launches"] += 1
+        c["flops"] += info["flops"]
+        c["bytes"] += info["bytes"]
+    frame_ms = sum(c["ms"] for c in classes.values())
+    peak_tf = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    rows = []
+    for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = c["ms"] * 1e-3
+        tf = c["flops"] / sec / 1e12 if sec > 0 else 0.0
+        gbs = c["bytes"] / sec / 1e9 if sec > 0 else 0.0
+        # which roof bounds this kernel: compare its arithmetic intensity with the ridge
+        ai = c["flops"] / max(c["bytes"], 1)
+        bound = "mfma" if ai > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+        rows.append({"kernel": name, "launches": c["launches"], "ms_per_frame": c["ms"],
+                     "share": c["ms"] / frame_ms if frame_ms else 0.0,
+                     "avg_launch_us": 1e3 * c["ms"] / c["launches"], "bound": bound,
+                     "tflops": tf, "gbs": gbs,
+                     "frac": (tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS)})
+    dom = rows[0]
+    if dom["bound"] == "mfma":
+        roofline = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak_tf, "unit": "TFLOP/s"}
+    else:
+        roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    tr, src = pmc_traffic(dom["kernel"])
+    roofline["traffic"] = tr
+    roofline["traffic_source"] = src
+    # durations: hipEvent pairs around every launch minus HALF the median cost of an empty event pair on this
+    # box (`event_gap_us`: two event packets, one of which overlaps a kernel) -- the correction that makes
+    # these averages agree with rocprofv3's of the same launches; raw sum kept as `kernel_sum_ms_raw`
+    roofline["timing"] = "hipEvent pair per launch minus half the empty-pair gap"
+    roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
+    roofline["kernel_sum_ms_raw"] = sum(getattr(eng, "last_raw_ms", []))
+    roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
+                     "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
+                     "kernel_sum_ms_per_frame": frame_ms})
+    return (rows, roofline, per_op) if want_ops else (rows, roofline)
 
 
 def video_rate(eng, style, d_s, H, W, batch, use_graph, n_frames=96):
@@ -312,21 +422,27 @@ def main():
 
     elapsed, blocks = timed_blocks(step, args.steps, dev, args.min_seconds)
 
-    def lanes_rate(bb, hh, ww, nsteps):
-        """frames/s of another (batch, size) on the same engine, `lanes` steps in flight, all ranks."""
+    def lanes_rate(bb, hh, ww, nsteps, engine=None, ds=None, n_lanes=None, note=None):
+        """frames/s of another (batch, size, engine, style degree) on this rank's GPU, `lanes` steps in flight, all ranks."""
+        e = engine or eng
+        dd = d_s if ds is None else ds
+        nl = n_lanes or lanes
         pl = [synth.synth_frames(bb, hh, ww, seed=5000 + 1000 * rank + i).to(dev) for i in range(2)]
         def st(i):
-            ln = i % lanes
+            ln = i % nl
             with torch.cuda.stream(streams[ln]):
-                return eng.forward(pl[i % 2], style, d_s, shared_style=True, use_graph=use_graph, lane=ln)
-        for i in range(lanes if emu else lanes + 2):
+                return e.forward(pl[i % 2], style, dd, shared_style=True, use_graph=use_graph, lane=ln)
+        for i in range(nl if emu else nl + 2):
             st(i)
-            if i < lanes:
+            if i < nl:
                 torch.cuda.synchronize()
         el, bl = timed_blocks(st, nsteps, dev, min(args.min_seconds, 0.5))
-        return {"value": ws * nsteps * bb / el, "unit": "frames/s", "frames_per_step_per_gpu": bb,
-                "ms_per_step": 1e3 * el / nsteps, "steps": nsteps, "blocks": len(bl), "frames_in_flight_per_gpu": lanes,
-                "workload": f"22x{hh}x{ww} -> 3x{4 * hh}x{4 * ww}"}
+        r = {"value": ws * nsteps * bb / el, "unit": "frames/s", "frames_per_step_per_gpu": bb,
+             "ms_per_step": 1e3 * el / nsteps, "steps": nsteps, "blocks": len(bl), "frames_in_flight_per_gpu": nl,
+             "workload": f"22x{hh}x{ww} -> 3x{4 * hh}x{4 * ww}"}
+        if note:
+            r["what"] = note
+        return r
 
     extras = {}
     if not args.no_extras:
@@ -335,9 +451,36 @@ def main():
         if emu:   # same control flow, toy sizes
             extras["batch4"] = lanes_rate(2, H, W, 2)
             extras["config3"] = lanes_rate(2, 16, 24, 2)
+            extras["config5"] = {"D_16x24": lanes_rate(1, 16, 24, 2)}
         else:
             extras["batch4"] = lanes_rate(4, H, W, 24)
             extras["config3"] = lanes_rate(4, 144, 256, max(8, 240 // ws))
+            # BASELINE config 5: 1536x1536 output and the demo's nominal non-square, non-power-of-two crop
+            # (vtoonify_model.py:250), VToonify-D, one frame per step
+            extras["config5"] = {"D_1536x1536": lanes_rate(1, 384, 384, 24),
+                                 "D_1440x1600": lanes_rate(1, 360, 400, 24)}
+    if not args.no_extras and ws == 1 and not emu:
+        # BASELINE config 4: VToonify-T (Toonify backbone) at 1024x1024 and the style-degree sweep.  T ignores d_s
+        # (model/vtoonify.py:238,257); on D d_s = 0 skips the 12 AdaResBlock convs (model/dualstylegan.py:40-41)
+        shapes_t = state_shapes("toonify")
+        eng_t = VToonifyEngine({k: v.to(dev) for k, v in synth.synth_state_dict(shapes_t, 0).items()}, "toonify", 256,
+                               dtype, dev)
+        c4 = {"T_1024x1024": lanes_rate(1, 256, 256, 40, engine=eng_t, note="VToonify-T, d_s ignored by the backbone")}
+        del eng_t
+        c4["D_d_s_sweep"] = {f"{v:g}": round(lanes_rate(1, 256, 256, 40, ds=v)["value"], 1) for v in (0.0, 0.25, 0.5, 0.75, 1.0)}
+        extras["config4"] = c4
+        # throughput in the reference's own precision: the fp32 engine (exact-fp32 MFMA, the parity mode)
+        if dtype != torch.float32:
+            eng32 = VToonifyEngine(sd_dev, args.backbone, 256, torch.float32, dev)
+            f32 = lanes_rate(1, H, W, 16, engine=eng32, note="fp32 end to end (v_mfma_f32_16x16x4_f32), the reference's precision")
+            f32["single_stream"] = lanes_rate(1, H, W, 12, engine=eng32, n_lanes=1)["value"]
+            rows32, roof32 = kernel_table(eng32, eng32.plan_for(1, H, W, True, d_s != 0.0), torch.float32, 2)
+            f32["roofline"] = roof32
+            f32["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows32[:4]]
+            extras["fp32"] = f32
+            del eng32
+        torch.cuda.empty_cache()
+        extras["op_surface"] = op_surface(dev)
 
     # the same workload with ONE frame in flight (latency view; not `value`)
     single = None
@@ -390,50 +533,7 @@ def main():
         fps = ws * args.steps * B / elapsed
         # ---- per-kernel timing (HIP events on the launch stream), dominant kernel ----------
         plan = eng.plan_for(B, H, W, True, d_s != 0.0)
-        if emu:   # no HIP events on the host: one conv entry stands in for the table
-            per_op = [(next(info for _, info, _, _ in plan.convs), 1.0)]
-        else:
-            per_op = eng.time_ops(plan, iters=max(1, args.op_iters), with_style=True)
-        classes = {}
-        for info, ms in per_op:
-            c = classes.setdefault(info["kernel"], {"ms": 0.0, "launches": 0, "flops": 0, "bytes": 0})
-            c["ms"] += ms
-            c["launches"] += 1
-            c["flops"] += info["flops"]
-            c["bytes"] += info["bytes"]
-        frame_ms = sum(c["ms"] for c in classes.values())
-        rows = []
-        for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
-            sec = c["ms"] * 1e-3
-            tf = c["flops"] / sec / 1e12 if sec > 0 else 0.0
-            gbs = c["bytes"] / sec / 1e9 if sec > 0 else 0.0
-            peak_tf = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-            # which roof bounds this kernel: compare its arithmetic intensity with the ridge
-            ai = c["flops"] / max(c["bytes"], 1)
-            bound = "mfma" if ai > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-            rows.append({"kernel": name, "launches": c["launches"], "ms_per_frame": c["ms"],
-                         "share": c["ms"] / frame_ms if frame_ms else 0.0,
-                         "avg_launch_us": 1e3 * c["ms"] / c["launches"], "bound": bound,
-                         "tflops": tf, "gbs": gbs,
-                         "frac": (tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS)})
-        dom = rows[0]
-        if dom["bound"] == "mfma":
-            roofline = {"bound": "mfma", "achieved": dom["tflops"],
-                        "peak": PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS,
-                        "unit": "TFLOP/s"}
-        else:
-            roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-        roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        roofline["traffic"] = pmc_traffic(dom["kernel"])
-        # durations: hipEvent pairs around every launch minus HALF the median cost of an empty event pair on this
-        # box (`event_gap_us`: two event packets, one of which overlaps a kernel) -- the correction that makes
-        # these averages agree with rocprofv3's of the same launches; raw sum kept as `kernel_sum_ms_raw`
-        roofline["timing"] = "hipEvent pair per launch minus half the empty-pair gap"
-        roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
-        roofline["kernel_sum_ms_raw"] = sum(getattr(eng, "last_raw_ms", []))
-        roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
-                         "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
-                         "kernel_sum_ms_per_frame": frame_ms})
+        rows, roofline, per_op = kernel_table(eng, plan, dtype, max(1, args.op_iters), emu=emu, want_ops=True)
         if args.kernels:
             for r in rows:
                 print(f"{r['kernel']:<36} n={r['launches']:3d} {r['ms_per_frame']:8.3f} ms {100 * r['share']:5.1f}% "
