@@ -827,6 +827,103 @@ def test_conv_whole_k_adain_chain(dev, dtype):
                  out=yA, ld_out=C, dtype=K.dt_code(dtype), tile_stats=ts)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16])   # bf16 only: an fp32 512-channel conv is two rounds (conv_fullk_kernel)
+def test_conv_weight_stationary_equals_whole_k(dev, dtype, monkeypatch):
+    """conv_fullkw_kernel (conv_fullkw.hpp): the whole-K conv with the weights resident in registers and G tiles of one
+    image streaming through a workgroup -- the batch form of the trunk convs (model/vtoonify.py:92-104,235-239 at
+    style_transfer.py:35's --batch_size 4).  It must be BIT-IDENTICAL to conv_fullk_kernel for every G: outputs, the
+    {mean, M2} tile records and tile pixel counts (vt_conv_desc.tile_stats), and the AdaIN-prologue consumer
+    (in_tile_stats); dilation 1/2/4, partial tiles, a ragged last group (tiles % G != 0), cout tail, two sources,
+    residual / d_s epilogue, planar output, batch with per-sample gamma/beta."""
+    import ctypes
+    from vtoonify_amd import _lib
+    g = np.random.default_rng(123)
+    unit = 256 if dtype == torch.float32 else 512          # single round: 8 wavefronts x one 128-byte row of channels
+    L = K.ACT_LRELU
+    P4 = 4 * P
+    cases = [  # (N, c0, c1, H, W, Cout, dil, act, resid, planar, stats)
+        (2, unit, 0, 17, 19, 136, 1, L, True, False, True),        # 3x3 tiles, partial edges, cout tail
+        (3, unit, 0, 9, 11, 64, 2, L, False, False, True),         # 4 phases x (1x1) tiles
+        (1, unit, 0, 13, 21, 40, 4, 0, True, False, True),         # 16 phases
+        (2, unit // 2, unit // 2, 10, 17, 32, 1, L, False, False, False),   # two sources (torch.cat of Fusion)
+        (1, unit, 0, 12, 9, 8, 1, K.ACT_RELU_TANH, False, True, False),      # planar fp32 output
+    ]
+    for N, c0, c1, H, W, Cout, dil, act, resid, planar, stats in cases:
+        cin = c0 + c1
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((Cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(Cout).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        wst = K.conv_weight_stream(wp)
+        if c1:
+            x0 = xt[..., :c0].contiguous()
+            x1 = torch.zeros((N, H, W, c1 + 16), dtype=dtype, device=dev)
+            x1[..., :c1] = xt[..., c0:]
+            srcs = dict(src0=x0, c0=c0, ld0=c0, src1=x1, c1=c1, ld1=c1 + 16)
+        else:
+            srcs = dict(src0=xt, c0=c0, ld0=c0)
+        ds = T(np.array([0.7], np.float32), dev)
+        r = None
+        if resid:
+            rn = g.standard_normal((N, Cout, H, W)).astype(np.float32)
+            r = K.nchw_to_nhwc(T(rn, dev), dtype, ld_out=Cout)
+        common = dict(n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, weight_stream=wst, cout=Cout, kh=3, kw=3, pad=dil,
+                      dil=dil, bias=T(b, dev), act=act, gain=2 ** 0.5 if act == L else 1.0, dtype=K.dt_code(dtype),
+                      alpha_dev=ds if resid else None, beta=1.0 if resid else 0.0, tile_hint=P4, **srcs)
+        res = {}
+        for G in (0, 1, 2, 4, 8):          # 0 = conv_fullk_kernel
+            monkeypatch.setenv("VT_FULLKW", "0" if G == 0 else "1")
+            monkeypatch.setenv("VT_FULLKW_MIN_G", "1")
+            monkeypatch.setenv("VT_FULLKW_G", str(max(G, 1)))
+            if planar:
+                out = torch.zeros((N, Cout, H, W), dtype=torch.float32, device=dev)
+                kw = dict(out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32)
+            else:
+                out = torch.zeros((N, H, W, Cout), dtype=dtype, device=dev)
+                kw = dict(out=out, ld_out=Cout, resid=r, ld_res=Cout)
+            ts = None
+            if stats:
+                ts = torch.full((K.conv_tile_stats_bytes(N, H, W, dil, Cout) // 4,), -7.0, dtype=torch.float32, device=dev)
+            d = K.make_conv_desc(tile_stats=ts, **kw, **common)
+            code = _lib.lib().vt_conv2d_tile(ctypes.byref(d))
+            # (a planar fp32 output stays on conv_fullk_kernel: the weight-stationary form has the lean NHWC epilogue only)
+            assert code // 100000000 == (4 if (G == 0 or planar) else 8), (code, G)
+            K.conv2d(tile_stats=ts, **kw, **common)
+            res[G] = (out.float().cpu().numpy().copy(), None if ts is None else ts.cpu().numpy().copy())
+        for G in (1, 2, 4, 8):
+            assert np.array_equal(res[G][0], res[0][0]), (N, H, W, dil, G, "output")
+            if stats:
+                assert np.array_equal(res[G][1], res[0][1]), (N, H, W, dil, G, "tile records")
+        assert np.abs(res[0][0]).max() > 0.1
+    # ---- AdaIN consumer: records of a dilation-dA producer -> conv of dilation dB, per-sample gamma/beta ----
+    for N, H, W, dA, dB in [(2, 17, 11, 1, 2), (2, 9, 20, 4, 1)]:
+        C = unit
+        x = g.standard_normal((N, C, H, W)).astype(np.float32)
+        wA = (g.standard_normal((C, C, 3, 3)) / math.sqrt(C * 9)).astype(np.float32)
+        wB = (g.standard_normal((48, C, 3, 3)) / math.sqrt(C * 9)).astype(np.float32)
+        gb = (1.0 + 0.3 * g.standard_normal((N, 2 * C))).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wpA, wpB = K.pack_conv_weight(T(wA, dev), out_dtype=dtype), K.pack_conv_weight(T(wB, dev), out_dtype=dtype)
+        sA, sB = K.conv_weight_stream(wpA), K.conv_weight_stream(wpB)
+        outs = {}
+        for G in (0, 2, 4):
+            monkeypatch.setenv("VT_FULLKW", "0" if G == 0 else "1")
+            monkeypatch.setenv("VT_FULLKW_MIN_G", "1")
+            monkeypatch.setenv("VT_FULLKW_G", str(max(G, 1)))
+            ts = torch.zeros(K.conv_tile_stats_bytes(N, H, W, dA, C) // 4, dtype=torch.float32, device=dev)
+            yA = torch.zeros((N, H, W, C), dtype=dtype, device=dev)
+            K.conv2d(src0=xt, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpA, weight_stream=sA, cout=C, kh=3,
+                     kw=3, pad=dA, dil=dA, act=L, gain=2 ** 0.5, out=yA, ld_out=C, dtype=K.dt_code(dtype), tile_stats=ts)
+            yB = torch.zeros((N, H, W, 48), dtype=dtype, device=dev)
+            K.conv2d(src0=yA, c0=C, ld0=C, n=N, h=H, w=W, out_h=H, out_w=W, weight=wpB, weight_stream=sB, cout=48, kh=3,
+                     kw=3, pad=dB, dil=dB, out=yB, ld_out=48, dtype=K.dt_code(dtype), tile_hint=P4, in_tile_stats=ts,
+                     in_stats_dil=dA, in_gb=T(gb, dev), in_ld_gb=2 * C)
+            outs[G] = yB.float().cpu().numpy().copy()
+        assert np.array_equal(outs[2], outs[0]) and np.array_equal(outs[4], outs[0]), (N, H, W, dA, dB)
+        assert np.abs(outs[0]).max() > 0.1
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose_blur_persistent_form(dev, dtype, monkeypatch):
     """Single-chunk layers with many tiles (the 1024^2 level) run persistent workgroups: weights resident in LDS,

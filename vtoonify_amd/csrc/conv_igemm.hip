@@ -1302,6 +1302,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 }
 
 #include "conv_fullk.hpp"
+#include "conv_fullkw.hpp"
 #include "conv_upblur.hpp"
 #include "conv_thin.hpp"
 #include "conv_c64.hpp"
@@ -1629,7 +1630,8 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 // ---------------------------------------------------------------------------------------
 struct TilePlan {
     int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp),
-               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp), 7 = persistent 64->64
+               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp), 7 = persistent 64->64,
+               // 8 = whole-K, weight-stationary over G tiles (conv_fullkw.hpp; bm = 64 * G)
     int bm, bn, splitk;
 };
 
@@ -1758,6 +1760,22 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
                 t.bm = FK_TH * FK_TW;
                 t.bn = FK_BN;
                 t.splitk = 1;
+                // a batch of frames: the weight-stationary form (conv_fullkw.hpp), G tiles of one image per workgroup.
+                // The ONE plan choice that looks at the batch -- allowed because the two kernels are bit-identical per
+                // frame for every G (tests/test_ops.py::test_conv_weight_stationary_equals_whole_k).
+                // VT_FULLKW=0 disables it; VT_FULLKW_MIN_G: smallest G that uses it (read per call: tests flip them)
+                int fkw_min_g = 2;
+                {
+                    const char* e = getenv("VT_FULLKW");
+                    const char* m = getenv("VT_FULLKW_MIN_G");
+                    if (m && atoi(m) > 0) fkw_min_g = atoi(m);
+                    if (e && e[0] == '0') fkw_min_g = 1 << 30;
+                }
+                FullkwArgs wg;
+                if (fullkw_eligible<T>(a, a.wstream, wg)) {
+                    const int G = fullkw_group(a.N, wg.groups_per_img, vt_cdiv(a.coutT, FK_BN));
+                    if (G >= fkw_min_g) t.kind = 8, t.bm = FK_TH * FK_TW * (G > 8 ? 8 : G);
+                }
                 return t;
             }
         }
@@ -1941,7 +1959,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         if (db) return launch_upblur<T, 32, 12, 1, 0, 0>(a, stream);
         return lb2 ? launch_upblur<T, 32, 12, 0, 0, 1>(a, stream) : launch_upblur<T, 32, 12, 0, 0, 0>(a, stream);
     }
-    if ((a.tile_stats || a.in_tile_stats) && t.kind != 4) {
+    if ((a.tile_stats || a.in_tile_stats) && t.kind != 4 && t.kind != 8) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);
         return VT_ERR_UNSUPPORTED;
     }
@@ -1954,6 +1972,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         return VT_ERR_UNSUPPORTED;
     }
     if (t.kind == 6) return launch_thin<T>(a, stream);
+    if (t.kind == 8) {
+        FullkwArgs wg;
+        if (!fullkw_eligible<T>(a, a.wstream, wg)) {
+            vt_set_error("vt_conv2d: weight-stationary whole-K kernel requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+        return launch_fullkw<T>(a, wg, t.bm / (FK_TH * FK_TW), stream);
+    }
     if (t.kind == 4) {
         FullkArgs fg;
         if (!fullk_eligible<T>(a, a.wstream, fg)) {

@@ -236,6 +236,13 @@ static inline void vt_glds16(const BufRsrc& r, void* lds_wave_base, uint32_t vof
         else memset(dst + 4 * d, 0, 4);
     }
 }
+// 4 bytes per lane: lane l's dword lands at lds_wave_base + 4 l
+static inline void vt_glds4(const BufRsrc& r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    unsigned char* dst = (unsigned char*)lds_wave_base + (size_t)emu::cur()->lane * 4;
+    const uint64_t off = (uint64_t)voff + soff;
+    if (off + 4 <= r.nrec) memcpy(dst, r.base + off, 4);
+    else memset(dst, 0, 4);
+}
 static inline void vt_glds_wait() {}
 template <int N>
 static inline void vt_glds_wait_n() {}
@@ -253,6 +260,10 @@ __device__ __forceinline__ BufRsrc vt_make_rsrc(const void* base, uint32_t nrec)
 }
 __device__ __forceinline__ void vt_glds16(const BufRsrc& r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                             voff, soff, 0, 0);
+}
+__device__ __forceinline__ void vt_glds4(const BufRsrc& r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4,
                                              voff, soff, 0, 0);
 }
 __device__ __forceinline__ void vt_glds_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0), expcnt/lgkmcnt untouched */ }
@@ -326,6 +337,97 @@ __device__ __forceinline__ void vt_vmcnt_fence() {
     static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
     __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
+// Identity the optimiser cannot see through: values derived from the result are recomputed where they are used
+// instead of being hoisted out of a loop and kept live (LLVM hoists every loop-invariant address / predicate; in a
+// kernel whose registers are full of resident operands those copies spill -- and a scratch reload is a VMEM round
+// trip behind the LDS-DMA in flight).
+#ifdef VT_EMU
+static inline int vt_opaque(int v) { return v; }
+#else
+__device__ __forceinline__ int vt_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#endif
+
+// ---------------------------------------------------------------------------------
+// Buffer loads / stores the COMPILER DOES NOT SEE (inline asm), for the per-step residual read and output write
+// of a kernel that keeps LDS-DMA loads in flight across steps: beside a pending `buffer_load ... lds` hipcc waits
+// vmcnt(0) at the first use of any ordinary load result (cdna_hip_programming.md, "pipelining across barriers"),
+// which drains the prefetch every step.  Same contract as vt_gload16_pair_hidden: the caller counts every
+// vector-memory operation of the wave and places vt_vmcnt_fence<N>() before the first read of a destination.
+// Offsets are range-checked by the descriptor (raw buffer: a dword at or beyond `nrec` reads as zero / is not
+// written), so a lane that has nothing to do passes GLDS-style out-of-range offsets and every wave issues the
+// same number of operations.  DW = dwords per lane (1, 2 or 4).
+// ---------------------------------------------------------------------------------
+#ifdef VT_EMU
+struct BufRaw {
+    char* base;
+    uint32_t nrec;
+};
+static inline BufRaw vt_make_raw(const void* base, uint32_t nrec) { return BufRaw{(char*)base, base ? nrec : 0u}; }
+template <int DW>
+static inline void vt_bload_hidden(u128& v, const BufRaw& r, uint32_t voff) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int d = 0; d < DW; ++d)
+        if ((uint64_t)voff + 4 * d + 4 <= r.nrec) memcpy(&w[d], r.base + voff + 4 * d, 4);
+    v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+}
+template <int DW, int AUX = 0>
+static inline void vt_bstore_hidden(const BufRaw& r, uint32_t voff, const u128& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (int d = 0; d < DW; ++d)
+        if ((uint64_t)voff + 4 * d + 4 <= r.nrec) memcpy(r.base + voff + 4 * d, &w[d], 4);
+}
+#else
+struct BufRaw {
+    vt_u32x4 v;   // V#: base[47:0], stride 0, num_records, raw 32-bit format (the words vt_make_rsrc builds)
+};
+__device__ __forceinline__ BufRaw vt_make_raw(const void* base, uint32_t nrec) {
+    const uint64_t a = (uint64_t)base;
+    BufRaw b;
+    b.v = vt_u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, base ? nrec : 0u, 0x00020000u};
+    return b;
+}
+template <int DW>
+__device__ __forceinline__ void vt_bload_hidden(u128& v, const BufRaw& r, uint32_t voff) {
+    static_assert(DW == 1 || DW == 2 || DW == 4, "dwords per lane");
+    if constexpr (DW == 4) {
+        vt_u32x4 x;
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(x) : "v"(voff), "s"(r.v));
+        v = __builtin_bit_cast(u128, x);
+    } else if constexpr (DW == 2) {
+        typedef uint32_t vt_u32x2 __attribute__((ext_vector_type(2)));
+        vt_u32x2 x;
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(x) : "v"(voff), "s"(r.v));
+        v.x = x.x, v.y = x.y, v.z = 0u, v.w = 0u;
+    } else {
+        uint32_t x;
+        asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=&v"(x) : "v"(voff), "s"(r.v));
+        v.x = x, v.y = 0u, v.z = 0u, v.w = 0u;
+    }
+}
+// AUX = cache policy of the store (A/B knob): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
+template <int DW, int AUX = 0>
+__device__ __forceinline__ void vt_bstore_hidden(const BufRaw& r, uint32_t voff, const u128& v) {
+    static_assert(DW == 2 || DW == 4, "dwords per lane");
+#define VT_BST(OP_, X_)                                                                                                   \
+    if constexpr (AUX == 1) asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen nt" ::"v"(X_), "v"(voff), "s"(r.v) : "memory");          \
+    else if constexpr (AUX == 2) asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen sc1" ::"v"(X_), "v"(voff), "s"(r.v) : "memory");    \
+    else if constexpr (AUX == 3) asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen sc0 sc1" ::"v"(X_), "v"(voff), "s"(r.v) : "memory"); \
+    else asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen" ::"v"(X_), "v"(voff), "s"(r.v) : "memory");
+    if constexpr (DW == 4) {
+        const vt_u32x4 x = __builtin_bit_cast(vt_u32x4, v);
+        VT_BST("buffer_store_dwordx4", x)
+    } else {
+        typedef uint32_t vt_u32x2 __attribute__((ext_vector_type(2)));
+        const vt_u32x2 x = {v.x, v.y};
+        VT_BST("buffer_store_dwordx2", x)
+    }
+#undef VT_BST
 }
 #endif
 

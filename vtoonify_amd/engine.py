@@ -465,7 +465,7 @@ class VToonifyEngine:
                                      out=tmp, ld_out=cf) for r in range(1, 7)]
             kinds.append(self._conv_kind(src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                                          weight=self.w[f"{rk}.0.conv2"], cout=cf, kh=3, kw=3, pad=1, out=tmp, ld_out=cf))
-            fuse_adain = all(k == 4 for k in kinds)
+            fuse_adain = all(k in (4, 8) for k in kinds)
         if fuse_adain:
             nb = max(K.conv_tile_stats_bytes(B, h, w, dd, cf) for dd in (1, 2, 4))
             ts = [self._buf(plan, f"tile_stats{i}", (nb // 4,), f32) for i in range(2)]
@@ -697,7 +697,7 @@ class VToonifyEngine:
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
             kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
                      3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel", 5: "conv_upblur_kernel",
-                     6: "conv_thin_kernel", 7: "conv3x3_c64_kernel"}[kind]
+                     6: "conv_thin_kernel", 7: "conv3x3_c64_kernel", 8: "conv_fullkw_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1 and self.lib.vt_conv2d_splitk_mode(C.byref(d)) == 2:
