@@ -385,7 +385,7 @@ def main():
     shapes = state_shapes(args.backbone)
     sd = synth.synth_state_dict(shapes, 0) if rank == 0 else None
     t0 = time.perf_counter()
-    sd_dev = frames.broadcast_state_dict(shapes, sd, dev)
+    sd_dev = frames.broadcast_state_dict(shapes, sd, dev, skip_unused=True)
     style, d_s = frames.broadcast_style(synth.synth_style(seed=17) if rank == 0 else None,
                                         args.d_s if rank == 0 else None, dev)
     torch.cuda.synchronize()
@@ -407,7 +407,7 @@ def main():
     def step(i):
         ln = i % lanes
         with torch.cuda.stream(streams[ln]):
-            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=ln)
+            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=ln, borrow=True)
 
     for i in range(max(args.warmup, lanes)):
         y = step(i)
@@ -431,7 +431,7 @@ def main():
         def st(i):
             ln = i % nl
             with torch.cuda.stream(streams[ln]):
-                return e.forward(pl[i % 2], style, dd, shared_style=True, use_graph=use_graph, lane=ln)
+                return e.forward(pl[i % 2], style, dd, shared_style=True, use_graph=use_graph, lane=ln, borrow=True)
         for i in range(nl if emu else nl + 2):
             st(i)
             if i < nl:
@@ -489,7 +489,7 @@ def main():
     if rank == 0 and (lanes > 1 or emu):
         n1 = min(args.steps, 1 if emu else 50)
         def s1(i):
-            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0)
+            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0, borrow=True)
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):

@@ -330,3 +330,24 @@ def test_plan_sweep_candidates_are_wellformed():
     assert c and all((h // 100000000) in (1, 2) for h in c) and 100000000 + 8 * 1000000 + 128128 in c
     assert all(h % 1000 <= 32 for h in ps.candidates("256x256:136->3:k3s1d1p1:nchw"))
     assert all(h // 100000000 == 2 for h in ps.candidates("64x64:512->512:k3s2d1p1"))
+
+
+@pytest.mark.parametrize("tag", ["D", "T"])
+def test_frame_path_never_reads_the_entries_the_broadcast_skips(dev, tag):
+    """frames.broadcast_state_dict(skip_unused=True) sends 104 M of the 166.6 M elements of the D checkpoint: the 4x4 ..
+    32x32 generator layers, the noise buffers and the structure transforms of latent rows 0-6 are replaced by zeros on
+    every rank (frames.inference_unused).  The frame -- and zplus2wplus -- must not change by a bit."""
+    from vtoonify_amd import frames
+    sd = synth.synth_state_dict(load_keys(tag), 0)
+    skipped = [k for k in sd if frames.inference_unused(k)]
+    assert len(skipped) > 50 and not any(k.startswith(("encoder.", "fusion_", "res.")) for k in skipped)
+    assert sum(sd[k].numel() for k in skipped) > 0.25 * sum(v.numel() for v in sd.values())
+    x = synth.synth_frames(1, 16, 16, seed=4).to(dev)
+    s = synth.synth_style(seed=6).to(dev)
+    dt = torch.bfloat16 if dev.type == "cpu" else torch.float32
+    full = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, BB[tag], 256, dt, dev)
+    y0, w0 = full.forward(x, s, 0.5), full.map_style(s)
+    del full
+    lean = VToonifyEngine({k: (torch.zeros_like(v) if frames.inference_unused(k) else v).to(dev) for k, v in sd.items()},
+                          BB[tag], 256, dt, dev)
+    assert torch.equal(lean.forward(x, s, 0.5), y0) and torch.equal(lean.map_style(s), w0)

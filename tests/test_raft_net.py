@@ -176,9 +176,29 @@ def test_video_size_pair_is_finite_and_deterministic():
     w = 1
     Is = torch.stack([base[0, :, 4 + k:516 + k, 4:516] for k in range(3)]).to(dev) * 2 - 1       # a slowly moving clip
     Ps = (torch.randn(3, 19, 512, 512, generator=g) * 4).to(dev)
-    flow_fn = lambda i1, i2: m((i1 + 1) * 255.0 / 2, (i2 + 1) * 255.0 / 2, iters=20, test_mode=True)[1]
+    flow_fn = smooth.raft_flow_fn(m, iters=20)      # smooth_parsing_map.py:154
     f1 = flow_fn(Is[1:2].repeat(3, 1, 1, 1), Is)
     assert tuple(f1.shape) == (3, 2, 512, 512) and bool(torch.isfinite(f1).all())
     assert torch.equal(f1, flow_fn(Is[1:2].repeat(3, 1, 1, 1), Is))
     y = smooth.smooth_parsing_maps(Is, Ps, flow_fn, w)
     assert tuple(y.shape) == (3, 19, 256, 256) and bool(torch.isfinite(y).all())
+    # ---- at the WORKING size and iteration count against the CPU oracle (a restatement of raft.py:86-144 pinned to
+    # reference-made goldens at the small size): 20 GRU iterations of exact-fp32 MFMA against torch-CPU convolutions.
+    # Stated drift bar: 2e-3 of max|flow| (the flows differ by summation order only; 3 iterations measure 6e-6).
+    import json
+    import os
+    from oracle import raft_oracle as R, vtoonify_oracle as O
+    O.set_backend("torch")
+    i1 = ((Is[1:2] + 1) * 255.0 / 2)
+    i2 = ((Is[2:3] + 1) * 255.0 / 2)
+    lo, up = m(i1, i2, iters=20, test_mode=True)
+    wl, wu = R.raft_forward(synth.to_numpy_sd(synth.synth_state_dict(load_keys("raft"), 0)), i1.cpu().numpy(),
+                            i2.cpu().numpy(), iters=20)
+    el, eu = rel_err(lo.cpu().numpy(), wl), rel_err(up.cpu().numpy(), wu)
+    print(f"[parity] RAFT 512x512 x 20 iterations: flow_low {el:.2e}, flow_up {eu:.2e}, max|flow| {np.abs(wu).max():.2f}")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"what": "RAFT 512x512 x 20 iterations flow_up vs oracle", "dtype": "float32",
+                                "max_rel": eu, "psnr_db": None, "shape": list(wu.shape)}) + "\n")
+    assert el < 2e-3 and eu < 2e-3, (el, eu)

@@ -137,6 +137,27 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         return (const unsigned char*)g.wstream + (size_t)((tile_n * nchunks + r * FK_NW + wave) * (NSUB * 2)) * 1024;
     };
 
+    // Epilogue constants of this thread (it finishes pixel tid >> 3, channels n0 + 4 * (tid & 7) ..+3), fetched BEFORE
+    // the main loop and in ONE branch.  The epilogue used to select "bias or 0" per element on a run-time condition:
+    // hipcc then branches around each load and waits vmcnt(0) per element -- four dependent L2 round trips (~2 us of a
+    // 10 us launch) at the very end of the kernel, where nothing overlaps them (round 3, found on conv_fullkw.hpp).
+    float ep_bias[4] = {0.f, 0.f, 0.f, 0.f}, ep_slope[4] = {p.slope, p.slope, p.slope, p.slope};
+    float ep_alpha = 1.0f;
+    {
+        const int en = n0 + 4 * (tid & 7);
+        if (en < p.coutT) {   // coutT % 8 == 0 (fullk_eligible): the four channels are all in or all out
+            if (p.bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ep_bias[i] = p.bias[en + i];
+            }
+            if (p.slope_vec) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ep_slope[i] = p.slope_vec[en + i];
+            }
+        }
+        if (p.alpha_dev) ep_alpha = p.alpha_dev[0];
+    }
+
     f32x4 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -303,13 +324,9 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     const int oy = y0 + (px >> 3) * d, ox = x0 + (px & 7) * d;
     const int n = n0 + 4 * c4;
     const bool live = oy < p.H && ox < p.W && n < p.coutT;
-    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    const float ga = p.gain_alpha * ep_alpha;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int nn = n + i;
-        const float bv = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
-        f[i] = conv_finish(p, f[i], bv, ga, (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope);
-    }
+    for (int i = 0; i < 4; ++i) f[i] = conv_finish(p, f[i], ep_bias[i], ga, ep_slope[i]);
     const int m = (img * p.H + oy) * p.W + ox;
     if (!p.tile_stats) {
         if (live) store_out4(p, m, n, f);

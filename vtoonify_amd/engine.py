@@ -65,6 +65,7 @@ class VToonifyEngine:
     state_dict: the reference's `g_ema` schema, fp32, on `device`.
     dtype: torch.bfloat16 (fast) or torch.float32 (parity mode, exact-fp32 MFMA).
     """
+    supports_borrow = True   # forward(..., borrow=True) hands out the plan's output buffer instead of a copy
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "dualstylegan",
                  in_size: int = 256, dtype: torch.dtype = torch.bfloat16,
@@ -86,6 +87,9 @@ class VToonifyEngine:
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
+        # VT_GRAPH_FIRST=1 (default): capture the hipGraph on the first call of a shape; 0 = on the second (one-off shapes
+        # then never pay a capture)
+        self.graph_first = os.environ.get("VT_GRAPH_FIRST", "1") != "0"
         self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
         # style path on a second stream / graph branch beside the encoder.  OFF by default: measured on one box
         # (same call) one frame in flight +1 % (style) / +5 % (style + thin), but three frames in flight -31 % /
@@ -116,7 +120,13 @@ class VToonifyEngine:
         while f"encoder.{self.n_down}.0.weight" in self.sd:
             self.n_down += 1
         self.n_fuse = sum(1 for lvl in range(5) if 2 ** (5 + lvl) <= in_size)
-        self._plans: Dict[tuple, _Plan] = {}
+        # plans are an LRU (a plan = activations + modulated weights + a hipGraph, ~0.7 GB at 22x256x256): an image-mode
+        # caller that feeds many crop sizes would otherwise grow memory without bound.  VT_MAX_PLANS
+        # overrides the bound (default 12: three lanes x four shapes).
+        import collections
+        self._plans: "collections.OrderedDict[tuple, _Plan]" = collections.OrderedDict()
+        self.max_plans = max(1, int(os.environ.get("VT_MAX_PLANS", "12")))
+        self._shape_seen: Dict[tuple, int] = {}
         self._pack_static()
 
     # ------------------------------------------------------------------ static weights
@@ -261,6 +271,7 @@ class VToonifyEngine:
         valid serial order (time_ops, emulation)."""
         forked = plan is not None and self.fork_thin and self.device.type == "cuda"
         cur = torch.cuda.current_stream(self.device) if forked else None
+        prev_thin = False   # branch of the previous op
         for fn, args, what in ops:
             st = stream
             if forked:
@@ -268,13 +279,16 @@ class VToonifyEngine:
                 if info.get("branch"):
                     if plan.thin is None:
                         plan.thin = torch.cuda.Stream(self.device)
-                    if not plan.thin_busy:
+                    if not prev_thin:   # EVERY main -> thin transition: the thin op may read what main just issued
                         plan.thin.wait_stream(cur)
-                        plan.thin_busy = True
+                    plan.thin_busy = True
+                    prev_thin = True
                     st = C.c_void_p(plan.thin.cuda_stream)
-                elif plan.thin_busy and info.get("join"):
-                    cur.wait_stream(plan.thin)
-                    plan.thin_busy = False
+                else:
+                    prev_thin = False
+                    if plan.thin_busy and info.get("join"):
+                        cur.wait_stream(plan.thin)
+                        plan.thin_busy = False
             rc = fn(*args, st)
             if rc != 0:
                 raise _lib.VtError(f"{self._info(what)['name']} failed (code {rc}): "
@@ -740,15 +754,13 @@ class VToonifyEngine:
         self._rows_ref, self._rows_ver, self._rows_val = owner, getattr(owner, "_version", 0), val
         return val
 
-    def _auto_lane(self) -> int:
-        """Lane for the calling HIP stream: frames issued on different streams must not share plan buffers."""
+    def _auto_lane(self):
+        """Lane for the calling HIP stream: frames issued on different streams must not share plan buffers.  Auto lanes
+        live in their own namespace ('s', stream id): they can never collide with the explicit integer lanes of
+        VideoToonifier / bench.py (a module call on stream X used to be able to get the plan of slot lane k)."""
         if self.device.type != "cuda":
             return 0
-        sid = torch.cuda.current_stream(self.device).cuda_stream
-        lanes = self.__dict__.setdefault("_stream_lanes", {})
-        if sid not in lanes:
-            lanes[sid] = len(lanes)
-        return lanes[sid]
+        return ("s", torch.cuda.current_stream(self.device).cuda_stream)
 
     def map_style(self, z: torch.Tensor) -> torch.Tensor:
         """VToonify.zplus2wplus (model/vtoonify.py:285-286): 8-layer mapping network."""
@@ -764,7 +776,7 @@ class VToonifyEngine:
     @torch.no_grad()
     def forward(self, x: torch.Tensor, style: torch.Tensor, d_s=None, return_mask: bool = False,
                 return_feat: bool = False, shared_style: Optional[bool] = None,
-                use_graph: Optional[bool] = None, lane: Optional[int] = None) -> torch.Tensor:
+                use_graph: Optional[bool] = None, lane: Optional[int] = None, borrow: bool = False) -> torch.Tensor:
         """`lane` selects an independent set of plan buffers (activations, split-K workspace, graph):
         frames issued on different HIP streams must use different lanes, so that two frames of a
         video can be in flight on one GPU (frames are independent).  None = one
@@ -799,6 +811,10 @@ class VToonifyEngine:
         if plan is None:
             plan = self._build_plan(B, H, W, bool(shared_style), has_res)
             self._plans[key] = plan
+            while len(self._plans) > self.max_plans:   # least recently used plan: its buffers and graph are dropped
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
         if cin != plan.cin0:
             raise _lib.VtError(f"expected {plan.cin0} input channels, got {cin}")
         # ---- per-call inputs into the plan's static buffers ---------------------------
@@ -810,19 +826,40 @@ class VToonifyEngine:
         # so the address cannot be recycled while it is the key.  Edits through `.data` bypass the version
         # counter: pass a new tensor (or cache_styles=False) for those.
         own = style_arg.device == self.device and style_arg.dtype == torch.float32
+        skey = (getattr(style_arg, "_version", 0), wspace, bool(shared_style))
         hit = (self.cache_styles and own and getattr(plan, "style_ref", None) is style_arg and
-               getattr(plan, "style_key", None) == (getattr(style_arg, "_version", 0), d_s, wspace, bool(shared_style)))
+               getattr(plan, "style_key", None) == skey + (d_s,))
         need_style = not hit
-        if "x_in" not in plan.bufs:
-            self._buf(plan, "x_in", (B, cin, H, W), torch.float32)
-        plan.bufs["x_in"].copy_(x.detach())
+        # the frame enters the plan through ONE layout kernel that reads the caller's tensor where it lies (fp32 / bf16 /
+        # fp16 NCHW, contiguous); anything else is first copied into a staging buffer.  (Round 2 always staged: a copy
+        # kernel per frame in front of the same layout kernel.)
+        xd = x.detach()
+        if not (xd.is_contiguous() and xd.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+            if "x_in" not in plan.bufs:
+                self._buf(plan, "x_in", (B, cin, H, W), torch.float32)
+            plan.bufs["x_in"].copy_(xd)
+            xd = plan.bufs["x_in"]
+        xn = plan.bufs["x_nhwc"]
+        _lib.check(self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xd.data_ptr()), B, cin,
+                                            H * W, K.dt_code(xd.dtype), self.dt, self._stream()), "vt_nchw_to_nhwc")
         if need_style:
-            plan.bufs["style_in"].copy_(srows)
-            plan.bufs["d_s"].fill_(d_s)
+            # the style rows and the style degree are uploaded only when they CHANGED (same caller tensor + version, same
+            # float): the style path below still recomputes everything from them every frame unless cache_styles is on
+            if not (own and getattr(plan, "up_ref", None) is style_arg and getattr(plan, "up_key", None) == skey):
+                plan.bufs["style_in"].copy_(srows)
+                plan.up_ref, plan.up_key = (style_arg, skey) if own else (None, None)
+            if getattr(plan, "up_ds", None) != d_s:
+                plan.bufs["d_s"].fill_(d_s)
+                plan.up_ds = d_s
             cacheable = self.cache_styles and own
             plan.style_ref = style_arg if cacheable else None
-            plan.style_key = (getattr(style_arg, "_version", 0), d_s, wspace, bool(shared_style)) if cacheable else None
-        if use_graph and self.device.type == "cuda" and not return_feat:
+            plan.style_key = skey + (d_s,) if cacheable else None
+        # a hipGraph is captured the SECOND time a (shape, lane) is seen: a one-off crop size runs eager launches and
+        # costs no warm-up frame, device sync and capture
+        seen = self._shape_seen[key] = self._shape_seen.get(key, 0) + 1
+        if len(self._shape_seen) > 4096:
+            self._shape_seen.clear()
+        if use_graph and self.device.type == "cuda" and not return_feat and (seen > 1 or plan.graphs or self.graph_first):
             self._replay(plan, need_style)
         else:
             self._launch(plan, need_style, not return_feat)
@@ -830,19 +867,17 @@ class VToonifyEngine:
             feat, cf, h, w = plan.feat
             f = K.nhwc_to_nchw(feat, cf, B, cf, h, w, self.dtype, torch.float32, self.device, feat)
             return f, plan.skip_enc.clone()
-        image = plan.image.clone()
+        # `borrow`: hand out the plan's own output buffer (valid until the next call on this lane) instead of a copy --
+        # for callers that consume the frame at once (video.py packs it to uint8 on the same stream; bench.py)
+        image = plan.image if borrow else plan.image.clone()
         if return_mask and self.dual:
-            return image, [m.clone() for m in plan.masks]
+            return image, [m if borrow else m.clone() for m in plan.masks]
         return image
 
     def _launch(self, plan: _Plan, with_style: bool, with_gen: bool = True):
-        """Issue the plan's kernels on the current stream (eager or under graph capture)."""
+        """Issue the plan's kernels on the current stream (eager or under graph capture).  The frame is already in
+        plan.bufs["x_nhwc"] (forward() converts the caller's tensor in place, outside the graph)."""
         stream = self._stream()
-        xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
-        B, cin, H, W = xin.shape
-        rc = self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()), B, cin,
-                                      H * W, K.VT_F32, self.dt, stream)
-        _lib.check(rc, "vt_nchw_to_nhwc")
         fork = with_style and self.fork_style and self.device.type == "cuda"
         if fork:
             # The style path (mapping MLPs, modulation) and the encoder share nothing until the generator: two
@@ -881,7 +916,14 @@ class VToonifyEngine:
 
     # ------------------------------------------------------------------ measurement hooks
     def plan_for(self, B: int, H: int, W: int, shared_style: bool = True, has_res: bool = True) -> _Plan:
-        return self._plans[(B, H, W, bool(shared_style), bool(has_res and self.dual))]
+        """The plan of a shape: lane 0's if it exists, else the most recently used one of any lane."""
+        key = (B, H, W, bool(shared_style), bool(has_res and self.dual))
+        if key in self._plans:
+            return self._plans[key]
+        for k in reversed(self._plans):
+            if k[:5] == key:
+                return self._plans[k]
+        raise KeyError(key)
 
     def frame_ops(self, plan: _Plan, with_style: bool = True):
         """Every launch of one frame, in order, as (fn, args, info) -- for per-kernel timing."""
@@ -923,9 +965,7 @@ class VToonifyEngine:
         return [(self._info(ops[i][2]), max(acc[i] / iters - 0.5 * self.event_gap_ms, 0.0)) for i in range(n)]
 
     def _launch_input_only(self, plan: _Plan, stream):
-        xin, xn = plan.bufs["x_in"], plan.bufs["x_nhwc"]
-        B, cin, H, W = xin.shape
-        _lib.check(self.lib.vt_nchw_to_nhwc(C.c_void_p(xn.data_ptr()), xn.shape[-1], C.c_void_p(xin.data_ptr()),
-                                            B, cin, H * W, K.VT_F32, self.dt, stream), "vt_nchw_to_nhwc")
+        """time_ops: the plan's x_nhwc still holds the last frame forward() converted -- nothing to do."""
+        return
 
     __call__ = forward

@@ -69,14 +69,35 @@ def batches(start: int, stop: int, batch_size: int) -> List[Tuple[int, int]]:
     return [(i, min(i + batch_size, stop)) for i in range(start, stop, batch_size)]
 
 
+_UNUSED = None
+
+
+def inference_unused(key: str) -> bool:
+    """Is this state_dict entry one that VToonify.forward never reads?  The generator's 4x4 .. 32x32 layers
+    (`conv1`, `convs.0-5`, `to_rgb1`, `to_rgbs.0-2`, the constant input: the frame enters at 32x32,
+    model/vtoonify.py:245-250), the zero noise buffers (:267), the structure-transform linears of latent rows 0-6
+    (`generator.res.0-6`: only rows 7-17 feed the synthesis convs, :221-224) and the FIR buffers of those layers.
+    They are 68 M of the 166.6 M elements of the D checkpoint: the weight broadcast skips them (zeros of the right
+    shape stand in, so the dict keeps the checkpoint's schema); tests/test_frames.py checks that zeroing them
+    leaves the output bit-identical."""
+    global _UNUSED
+    if _UNUSED is None:
+        import re
+        _UNUSED = re.compile(r"^generator\.(generator\.)?(conv1\.|to_rgb1\.|input\.|noises\.|convs\.[0-5]\.|to_rgbs\.[0-2]\.)"
+                             r"|^generator\.res\.[0-6]\.")
+    return _UNUSED.match(key) is not None
+
+
 def broadcast_state_dict(shapes: Dict[str, Tuple[int, ...]], sd: Optional[Dict[str, torch.Tensor]],
                          device: torch.device, src: int = 0,
-                         bucket_elems: int = 64 << 20) -> Dict[str, torch.Tensor]:
+                         bucket_elems: int = 64 << 20, skip_unused: bool = False) -> Dict[str, torch.Tensor]:
     """Broadcast an fp32 state_dict from `src` to every rank as a few large flat buckets
     (xGMI is point-to-point: few large messages, not 399 small ones).  `shapes` (key -> shape)
     is known on every rank (it is the checkpoint schema); only `src` needs `sd`.
-    Returns tensors on `device`, views into the received buckets."""
-    keys = sorted(shapes)
+    Returns tensors on `device`, views into the received buckets.  skip_unused: entries the frame path never
+    reads (inference_unused) are not sent -- every rank gets zeros of their shape (D: 393 MB instead of 666 MB;
+    the values that ARE sent stay fp32, so every rank packs / modulates exactly what a single GPU would)."""
+    keys = sorted(k for k in shapes if not (skip_unused and inference_unused(k)))
     # every tensor starts on a 256-byte boundary of its bucket: the kernels' 16-byte vector paths (weights of the
     # style MLP, FIR taps ...) apply to the views exactly as they do to separately allocated parameters
     ALIGN = 64
@@ -105,6 +126,10 @@ def broadcast_state_dict(shapes: Dict[str, Tuple[int, ...]], sd: Optional[Dict[s
             out[k] = flat[off:off + m].view(shapes[k])
             off += _padded(k)
         i = j
+    if skip_unused:
+        for k in shapes:
+            if k not in out:
+                out[k] = torch.zeros(shapes[k], dtype=torch.float32, device=device)
     return out
 
 

@@ -6,9 +6,10 @@ flicker-reduction pre-pass, smooth_parsing_map.py.
     fuse_window(...)                  :155-167, one centre frame: warp + spatial x temporal weights + fusion + Downsample
     smooth_parsing_maps(...)          :125-168, the loop over a video, with the optical flow supplied by a callable
 
-The optical-flow network itself (RAFT, model/raft/core/raft.py) is NOT built here: `flow_fn(image1, image2)` is
-whatever produces `flow_up` for a batch of frame pairs -- the reference's own `raft_model(..., test_mode=True)[1]`
-plugs in unchanged (its correlation lookup then runs on vtoonify_amd.raft_corr).  GPU fp32 tensors only.
+The optical flow comes from a callable `flow_fn(image1, image2) -> flow_up` for a batch of frame pairs: by default
+`raft_flow_fn(vtoonify_amd.raft.RAFT(...))` (the network of model/raft/core/raft.py on the same kernels, section 4.7 of
+DESIGN.md); the reference's own `raft_model(..., test_mode=True)[1]` plugs in unchanged as well (its correlation
+lookup then runs on vtoonify_amd.raft_corr).  GPU fp32 tensors only.
 """
 from __future__ import annotations
 
@@ -83,6 +84,14 @@ def fuse_window(image1: torch.Tensor, image2: torch.Tensor, parsing: torch.Tenso
     kern = make_downsample_kernel().to(parsing.device) if down_kernel is None else down_kernel
     # Downsample.forward: upfirdn2d(x, kernel, up=1, down=2, pad=(p+1)//2, p//2) with p = 4 - 2 (model.py:62-71)
     return op.upfirdn2d(fused, kern, up=1, down=2, pad=(1, 1))
+
+
+def raft_flow_fn(raft_model, iters: int = 20) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    """flow_fn of smooth_parsing_maps from a RAFT module (vtoonify_amd.raft.RAFT or the reference's):
+    smooth_parsing_map.py:150-151 calls `raft_model((image1+1)*255/2, (image2+1)*255/2, iters=20, test_mode=True)[1]`."""
+    def fn(image1: torch.Tensor, image2: torch.Tensor) -> torch.Tensor:
+        return raft_model((image1 + 1) * 255.0 / 2, (image2 + 1) * 255.0 / 2, iters=iters, test_mode=True)[1]
+    return fn
 
 
 def smooth_parsing_maps(Is: torch.Tensor, Ps: torch.Tensor, flow_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],

@@ -175,8 +175,10 @@ class VideoToonifier:
             rgb = frame_pack(slot.d_frames[:n], None, self.bgr, out=slot.d_rgb[:n])
             self.parsing_engine.parsing_maps(rgb, use_graph=self.use_graph, lane=slot.lane, out=slot.d_parsing[:n])
         x = frame_pack(slot.d_frames[:n], slot.d_parsing[:n] if pc else None, self.bgr, out=slot.d_x[:n])
+        # the frame is converted to uint8 by the next launch on this stream: borrow the engine's output buffer
+        kw = {"borrow": True} if getattr(self.engine, "supports_borrow", False) else {}
         y = self.engine.forward(x, self.style, self.d_s, shared_style=True, use_graph=self.use_graph,
-                                lane=slot.lane)
+                                lane=slot.lane, **kw)
         frame_unpack(y, self.bgr, out=slot.d_out[:n])
 
     # -- public -----------------------------------------------------------------------------

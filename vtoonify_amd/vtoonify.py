@@ -12,6 +12,7 @@ bit-identical to it -- real use loads a checkpoint.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -168,8 +169,18 @@ def _fusion(c):
 class VToonify(nn.Module):
     def __init__(self, in_size=256, out_size=1024, img_channels=3, style_channels=512, num_mlps=8,
                  channel_multiplier=2, num_res_layers=6, backbone="dualstylegan",
-                 compute_dtype: torch.dtype = torch.bfloat16):
+                 compute_dtype: Optional[torch.dtype] = None):
+        """compute_dtype: the arithmetic the frame runs in.  None = the environment variable VTOONIFY_AMD_DTYPE
+        ("fp32" | "bf16"), default **fp32** -- the reference's own precision (it is fp32 end to end,
+        model/stylegan/op/upfirdn2d_kernel.cu:311), so `style_transfer.py` on this package computes what it computes on
+        the reference to ~5e-6.  bf16 (3-4x the frames/s; PSNR >= 45 dB against the fp32 path) is an
+        explicit choice: VToonify(..., compute_dtype=torch.bfloat16) or VTOONIFY_AMD_DTYPE=bf16."""
         super().__init__()
+        if compute_dtype is None:
+            env = os.environ.get("VTOONIFY_AMD_DTYPE", "fp32").lower()
+            if env not in ("fp32", "float32", "bf16", "bfloat16"):
+                raise ValueError(f"VTOONIFY_AMD_DTYPE={env!r}: expected fp32 or bf16")
+            compute_dtype = torch.bfloat16 if env.startswith("b") else torch.float32
         self.backbone = backbone
         self.in_size = in_size
         self.style_channels = style_channels
@@ -227,13 +238,14 @@ class VToonify(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _probe(self):
-        # cheap per-call fingerprint: a `.to()` / re-assignment of a SUBMODULE's parameters moves the first and
-        # last storage of the model without passing through this module's _apply
-        ps = self.__dict__.get("_probe_params")
-        if ps is None:
-            allp = list(self.parameters())
-            ps = self.__dict__["_probe_params"] = (allp[0], allp[len(allp) // 2], allp[-1])
-        return tuple((p.device, p.data_ptr(), p._version) for p in ps)
+        """Fingerprint of EVERY parameter and buffer (device, storage address, in-place version counter), ~400 entries
+        per call: a `.to()` or re-assignment of a submodule (`model.generator = ...`), and an in-place edit of any
+        parameter (`p.mul_(...)`, `p.copy_(...)`), all change it and drop the packed weights.  Only edits through
+        `.data` escape the version counters -- those need invalidate()."""
+        h = 0
+        for t in self.state_dict(keep_vars=True).values():
+            h = (h * 1000003 + hash((t.device, t.data_ptr(), t._version))) & 0xFFFFFFFFFFFFFFF
+        return h
 
     def engine(self) -> VToonifyEngine:
         if self._engine is not None and self._engine_probe != self._probe():
