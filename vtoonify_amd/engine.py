@@ -916,10 +916,13 @@ class VToonifyEngine:
 
     # ------------------------------------------------------------------ measurement hooks
     def plan_for(self, B: int, H: int, W: int, shared_style: bool = True, has_res: bool = True) -> _Plan:
-        """The plan of a shape: lane 0's if it exists, else the most recently used one of any lane."""
+        """The plan of a shape: lane 0's if it exists, else the calling stream's own, else the most recently used."""
         key = (B, H, W, bool(shared_style), bool(has_res and self.dual))
         if key in self._plans:
             return self._plans[key]
+        auto = self._auto_lane()
+        if auto and key + (auto,) in self._plans:
+            return self._plans[key + (auto,)]
         for k in reversed(self._plans):
             if k[:5] == key:
                 return self._plans[k]
