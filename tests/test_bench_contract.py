@@ -43,8 +43,9 @@ def test_bench_single_process():
     # extra keys: the reference's --batch_size 4, config 3's per-rank step, one frame in flight, and the
     # drop-in module's __call__ (hipGraph by default: within 15 % of the engine's single-stream rate here,
     # short run; the 1-second default run is what DESIGN.md quotes)
-    for k in ("batch4", "config3", "single_stream", "module_call"):
+    for k in ("batch1", "config3", "single_stream", "module_call"):
         assert d[k]["value"] > 30.0, k
+    assert d["config"]["frames_per_step_per_gpu"] == 4
     assert d["timed_blocks"] >= 1 and d["timed_seconds"] > 0
     assert d["module_call"]["value"] > 0.85 * d["single_stream"]["value"], (d["module_call"], d["single_stream"])
 
@@ -68,7 +69,7 @@ def test_bench_two_ranks_dry_run_gloo_emulation():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--dry-run-emu", "--height", "8", "--width", "8", "--lanes", "1", "--min-seconds", "0",
-           "--dtype", "bf16", "--backbone", "toonify"]
+           "--dtype", "bf16", "--backbone", "toonify", "--batch", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -76,6 +77,6 @@ def test_bench_two_ranks_dry_run_gloo_emulation():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["data"] == "dry-run" and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "frame-parallel x2" and d["value"] > 0
-    for k in ("batch4", "config3", "single_stream", "module_call"):
+    for k in ("batch1", "config3", "single_stream", "module_call"):
         assert d[k]["value"] > 0, k
     assert d["cpu_baseline"] is None

@@ -151,6 +151,13 @@ __device__ __forceinline__ void unpack16<bf16_t>(u128 v, float* f) {
     f[6] = vt_u2f(v.w << 16);
     f[7] = vt_u2f(v.w & 0xffff0000u);
 }
+template <>
+__device__ __forceinline__ void unpack16<f16_t>(u128 v, float* f) {
+    f16_t h[8];
+    memcpy(h, &v, 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = to_f32(h[i]);
+}
 template <typename T>
 __device__ __forceinline__ u128 pack16(const float* f);
 template <>
@@ -350,6 +357,24 @@ static inline int vt_opaque(int v) { return v; }
 __device__ __forceinline__ int vt_opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+#endif
+
+// 16-byte range-checked load into registers (compiler-visible): bytes at or beyond the descriptor's size -- and
+// "negative" offsets, which wrap to huge unsigned ones -- read as zero, so a kernel may fetch whole aligned 16-byte
+// chunks around a row whose first and last elements are not 16-byte aligned without touching foreign memory.
+#ifdef VT_EMU
+static inline u128 vt_bload16(const BufRsrc& r, uint32_t voff) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int d = 0; d < 4; ++d)
+        if ((uint64_t)voff + 4 * d + 4 <= r.nrec) memcpy(&w[d], r.base + voff + 4 * d, 4);
+    u128 v;
+    v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+    return v;
+}
+#else
+__device__ __forceinline__ u128 vt_bload16(const BufRsrc& r, uint32_t voff) {
+    return __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
 }
 #endif
 
