@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 3
+#define VT_ABI_VERSION 4
 
 enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
@@ -189,6 +189,11 @@ typedef struct vt_conv_desc {
      * RAFT's SepConvGRU (model/raft/core/update.py:37-42: padding (0,2) / (2,0)); `pad` is then the vertical one.
      * Such convs run on the register-staged kernel. */
     int32_t pad_w_p1;
+    /* ABI 4: != 0 together with rgb_weight: only the fused ToRGB image (rgb_out) is written, the C-channel activation
+     * is NOT stored (`out` is ignored).  The last synthesis level's StyledConv output feeds nothing but its ToRGB
+     * (model/stylegan/model.py:364-392, model/vtoonify.py:269-272): 67 MB per 1024^2 frame that the reference writes
+     * and nobody reads.  Supported by the persistent 32 -> 32 kernel (KIND 3); VT_ERR_UNSUPPORTED elsewhere. */
+    int32_t rgb_only;
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);

@@ -344,6 +344,19 @@ def test_conv_fused_torgb(dev, dtype):
                  tile_hint=hint, rgb_weight=wrp, rgb_bias=T(br, dev), rgb_resid=rgb, rgb_out=rgb)
         assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), y_ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
         assert rel_err(rgb.cpu().numpy(), rgb_ref) < tol, (cin, cout, hint)
+        if (cin, cout) == (32, 32) and dtype == torch.bfloat16:
+            # vt_conv_desc.rgb_only (ABI 4): the last level's activation is not stored -- same image, `out` untouched
+            out2 = torch.full((2, H, W, cout), 7.0, dtype=dtype, device=dev)
+            rgb2 = T(skip.copy(), dev)
+            K.conv2d(src0=xt, c0=cin, ld0=cin, n=2, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out2, ld_out=cout, dtype=K.dt_code(dtype),
+                     tile_hint=hint, rgb_weight=wrp, rgb_bias=T(br, dev), rgb_resid=rgb2, rgb_out=rgb2, rgb_only=1)
+            assert torch.equal(rgb2, rgb) and bool((out2 == 7.0).all())
+        elif (cin, cout) == (64, 64):
+            with pytest.raises(Exception, match="rgb_only"):
+                K.conv2d(src0=xt, c0=cin, ld0=cin, n=2, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3,
+                         pad=1, out=out, ld_out=cout, dtype=K.dt_code(dtype), tile_hint=hint, rgb_weight=wrp,
+                         rgb_bias=T(br, dev), rgb_resid=rgb, rgb_out=rgb, rgb_only=1)
     # more channels than one tile: refused (the engine then issues ToRGB as its own conv)
     xt = K.nchw_to_nhwc(T(g.standard_normal((1, 64, 8, 8)).astype(np.float32), dev), dtype)
     wp = K.pack_conv_weight(T((g.standard_normal((256, 64, 3, 3)) / 24).astype(np.float32), dev), out_dtype=dtype)

@@ -15,7 +15,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
-ABI_VERSION = 3   # VT_ABI_VERSION of include/vtoonify_amd.h
+ABI_VERSION = 4   # VT_ABI_VERSION of include/vtoonify_amd.h
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_NCHW = 0, 1
@@ -54,7 +54,7 @@ class ConvDesc(C.Structure):
         ("weight_stream", C.c_void_p),
         ("tile_stats", C.c_void_p), ("in_tile_stats", C.c_void_p), ("in_stats_dil", C.c_int32),
         ("in_gb", C.c_void_p), ("in_ld_gb", C.c_int32),
-        ("up_fir", C.c_void_p), ("pad_w_p1", C.c_int32),
+        ("up_fir", C.c_void_p), ("pad_w_p1", C.c_int32), ("rgb_only", C.c_int32),
     ]
 
 

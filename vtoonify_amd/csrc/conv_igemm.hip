@@ -84,6 +84,7 @@ struct ConvArgs {
     const float* in_gb;
     int in_ld_gb;
     const float* up_fir;        // conv_transpose2d(stride 2) + blur form (conv_upblur.hpp) or NULL
+    int rgb_only;               // vt_conv_desc.rgb_only: the C-channel output is not stored (fused ToRGB only)
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -1279,7 +1280,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                     }
                 }
                 // one 16-byte store per lane: the four lane groups write the pixel's 64 bytes
-                if (m >= 0) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + q * 8, pack16<bf16_t>(f));
+                if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + q * 8, pack16<bf16_t>(f));
                 if (rgbf) {
                     if (p.dbg != 3) {
                     r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
@@ -1936,6 +1937,10 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
     }
+    if (a.rgb_only && t.kind != 3) {
+        vt_set_error("vt_conv2d: rgb_only needs the persistent 32 -> 32 kernel (plan kind %d)", t.kind);
+        return VT_ERR_UNSUPPORTED;
+    }
     if (t.kind == 5) {
         // deep layers (>= 4 channel chunks): double-buffered chunks, one workgroup per CU; shallow ones: single
         // stage, two workgroups per CU
@@ -2104,6 +2109,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.alpha_dev = d->alpha_dev;
     a.post_relu = d->post_relu ? 1 : 0;
     a.wstream = d->weight_stream;
+    a.rgb_only = (d->rgb_only && d->rgb_weight) ? 1 : 0;
     a.tile_stats = (float*)d->tile_stats;
     a.in_tile_stats = (const float*)d->in_tile_stats;
     a.in_stats_dil = d->in_stats_dil > 0 ? d->in_stats_dil : 1;

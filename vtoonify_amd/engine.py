@@ -226,6 +226,8 @@ class VToonifyEngine:
         cout_t = d.cout * d.phases
         macs = m * cout_t * d.kh * d.kw * cin if ref_macs is None else ref_macs
         osz = 4 if d.out_dtype == K.VT_F32 else 2
+        # ALGORITHMIC bytes: every operand read once + the output written once -- also when rgb_only skips that write
+        # (the op granularity of SURVEY.md 8d; the launch then moves fewer bytes than it is credited with)
         nbytes = (d.n * d.h * d.w * cin * self.esz + cout_t * d.kh * d.kw * cin * self.esz +
                   m * cout_t * osz * (2 if d.resid else 1))
         info = {"name": "conv", "kernel": "conv_igemm", "flops": 2 * macs, "bytes": nbytes, "cin": cin,
@@ -673,7 +675,12 @@ class VToonifyEngine:
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
-                self._op_conv(ops, plan, join=fuse_rgb, **same_kw, **(rgb_kw if fuse_rgb else {}))
+                # the LAST level's activation feeds nothing but its ToRGB: with the fused epilogue on the persistent 32 -> 32
+                # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only).  VT_RGB_ONLY=0: A/B.
+                rgb_only = (fuse_rgb and lvl == 4 and tile // 100000000 == 3 and
+                            os.environ.get("VT_RGB_ONLY", "1") != "0")
+                self._op_conv(ops, plan, join=fuse_rgb, **same_kw, **(rgb_kw if fuse_rgb else {}),
+                              **({"rgb_only": 1} if rgb_only else {}))
                 if not fuse_rgb:
                     self._op_conv(ops, plan, join=True, src0=o2.data_ptr() + b0 * 4 * hw * c1o * self.esz, c0=c1o, ld0=c1o, n=nb,
                                   h=2 * h, w=2 * w, out_h=2 * h, out_w=2 * w, weight=wm3, cout=3, kh=1, kw=1,
