@@ -48,6 +48,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int A_BYTES = PA * NWAVES * 1024;                  // 56 / 32 KB per buffer
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES];
     __shared__ float rgbx[NWM][TM][16][3];                       // ToRGB partials of the upper channel half
+    __shared__ __attribute__((aligned(16))) float epc[4][64];    // epilogue constants: bias, 3 rows of ToRGB weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -98,9 +99,22 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
         }
     };
 
-    // (bias and ToRGB weights are re-read per tile in the epilogue -- L1-resident, 32 values per lane: holding them
-    //  across the tap loop next to the 144 weight registers spilled 67 dwords, 43 scratch accesses inside the loop)
+    // Bias and ToRGB weights (32 values per lane) cannot stay in registers next to the 144 weight registers (held
+    // across the tap loop they spilled 67 dwords).  Round 2 re-read them from global memory per tile, each behind a
+    // per-element "pointer or 0" select: hipcc branches around every such load and waits vmcnt(0) for it -- 32
+    // dependent L2 round trips per TILE (the "+14-26 us of the fused ToRGB epilogue").  They are staged in LDS once per
+    // workgroup instead and read back per tile with eight 16-byte LDS reads.
     const bool rgbf = p.rgb_w != nullptr;
+    if (tid < 256) {
+        const int row = tid >> 6, c = tid & 63;
+        float v = 0.0f;
+        if (row == 0) {
+            if (p.bias) v = p.bias[c];
+        } else if (rgbf) {
+            v = to_f32(((const T*)p.rgb_w)[(row - 1) * 64 + c]);
+        }
+        epc[row][c] = v;   // (read after the tile loop's first barrier)
+    }
     const float rb0 = (rgbf && p.rgb_bias) ? p.rgb_bias[0] : 0.0f, rb1 = (rgbf && p.rgb_bias) ? p.rgb_bias[1] : 0.0f,
                 rb2 = (rgbf && p.rgb_bias) ? p.rgb_bias[2] : 0.0f;
 
@@ -174,16 +188,17 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
         }
         {
             const float ga = p.gain_alpha;
+            // this lane's 8 consecutive channels wn*32 + 8q .. +7: fragment 0 holds the first four, fragment 1 the rest
             float rwt[3][TN][4], bvr[TN][4];
+            {
+                const int ch = wn * 32 + q * 8;
+                unpack16<float>(ld128(&epc[0][ch]), bvr[0]);
+                unpack16<float>(ld128(&epc[0][ch + 4]), bvr[1]);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int ch = wn * 32 + frag_channel<true>(b, q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias ? p.bias[ch + i] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) rwt[j][b][i] = rgbf ? to_f32(((const T*)p.rgb_w)[j * 64 + ch + i]) : 0.0f;
+                for (int j = 0; j < 3; ++j) {
+                    unpack16<float>(ld128(&epc[1 + j][ch]), rwt[j][0]);
+                    unpack16<float>(ld128(&epc[1 + j][ch + 4]), rwt[j][1]);
+                }
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {

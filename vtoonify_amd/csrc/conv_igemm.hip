@@ -466,12 +466,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         for (int h = 0; h < BS; ++h) {
             const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b0 + h, q);
             nh[h] = n;
+            // bias / per-channel slope: ONE wave-uniform branch per table and unconditional loads at clamped indices
+            // inside it.  (The per-element form `(ptr && nn < coutT) ? ptr[co] : 0` makes hipcc branch around every load
+            // and wait vmcnt(0) for it: 4 x TN dependent L2 round trips at the end of every workgroup.)
+            int coi[4];
+            bool okc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int nn = n + i;
-                const int co = (p.phases > 1) ? nn % p.cout : nn;
-                bv[h][i] = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
-                sv[h][i] = (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope;
+                okc[i] = nn < p.coutT;
+                const int nc = okc[i] ? nn : 0;
+                coi[i] = (p.phases > 1) ? nc % p.cout : nc;
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[h][i] = p.bias[coi[i]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[h][i] = 0.0f;
+            }
+            if (p.slope_vec) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sv[h][i] = p.slope_vec[coi[i]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sv[h][i] = p.slope;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!okc[i]) bv[h][i] = 0.0f, sv[h][i] = p.slope;
             }
             if (rgbf) {   // wave-uniform: convs without the fusion pay one scalar branch per fragment column
 #pragma unroll

@@ -165,13 +165,24 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ky[i] *= inv;
         const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+        // (one wave-uniform branch per table, unconditional loads at clamped indices: a per-element "pointer or 0"
+        // select costs a dependent L2 round trip per element)
+        float slv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) bv[k] = 0.0f, slv[k] = p.slope;
+        if (p.bias) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) bv[k] = p.bias[nch + k < p.coutT ? nch + k : 0];
+        }
+        if (p.slope_vec) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) slv[k] = p.slope_vec[nch + k < p.coutT ? nch + k : 0];
+        }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const int nn = nch + k;
-            bv[k] = (p.bias && nn < p.coutT) ? p.bias[nn] : 0.0f;
-            const float sl = (p.slope_vec && nn < p.coutT) ? p.slope_vec[nn] : p.slope;
+            if (nch + k >= p.coutT) bv[k] = 0.0f, slv[k] = p.slope;
             gpos[k] = ga;
-            gneg[k] = (p.act == VT_ACT_LRELU) ? ga * sl : ga;
+            gneg[k] = (p.act == VT_ACT_LRELU) ? ga * slv[k] : ga;
         }
     };
     if (PERSIST) blur_consts();
