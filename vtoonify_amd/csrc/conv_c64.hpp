@@ -115,8 +115,8 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
         }
         epc[row][c] = v;   // (read after the tile loop's first barrier)
     }
-    const float rb0 = (rgbf && p.rgb_bias) ? p.rgb_bias[0] : 0.0f, rb1 = (rgbf && p.rgb_bias) ? p.rgb_bias[1] : 0.0f,
-                rb2 = (rgbf && p.rgb_bias) ? p.rgb_bias[2] : 0.0f;
+    float rb0 = 0.0f, rb1 = 0.0f, rb2 = 0.0f;
+    if (rgbf && p.rgb_bias) rb0 = p.rgb_bias[0], rb1 = p.rgb_bias[1], rb2 = p.rgb_bias[2];
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;

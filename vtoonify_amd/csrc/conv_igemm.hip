@@ -1204,21 +1204,30 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 
     // fused-ToRGB constants in registers for the life of the workgroup
     const bool rgbf = p.rgb_w != nullptr;
+    // (one wave-uniform branch per table with all of its loads inside: the per-element "pointer ? load : 0" form is a
+    // dependent L2 round trip per element -- 35 of them ahead of the first tile of every persistent workgroup)
     float rwt[3][TN][4];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rwt[j][b][i] = rgbf ? to_f32(((const T*)p.rgb_w)[j * 32 + frag_channel<true>(b, q) + i]) : 0.0f;
     float bvr[TN][4];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias ? p.bias[frag_channel<true>(b, q) + i] : 0.0f;
-    const float rb0 = (rgbf && p.rgb_bias) ? p.rgb_bias[0] : 0.0f, rb1 = (rgbf && p.rgb_bias) ? p.rgb_bias[1] : 0.0f,
-                rb2 = (rgbf && p.rgb_bias) ? p.rgb_bias[2] : 0.0f;
+        for (int i = 0; i < 4; ++i) bvr[b][i] = rwt[0][b][i] = rwt[1][b][i] = rwt[2][b][i] = 0.0f;
+    if (rgbf) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rwt[j][b][i] = to_f32(((const T*)p.rgb_w)[j * 32 + frag_channel<true>(b, q) + i]);
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias[frag_channel<true>(b, q) + i];
+    }
+    float rb0 = 0.0f, rb1 = 0.0f, rb2 = 0.0f;
+    if (rgbf && p.rgb_bias) rb0 = p.rgb_bias[0], rb1 = p.rgb_bias[1], rb2 = p.rgb_bias[2];
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -1383,12 +1392,29 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvArgs 
                 }
             }
         }
+        {
+            float bv8[8], sv8[8];
+            int co8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int nn = n + i;
-            const int co = (p.phases > 1) ? nn % p.cout : nn;
-            const float bv = (p.bias && nn < p.coutT) ? p.bias[co] : 0.0f;
-            f[i] = conv_finish(p, f[i], bv, ga, (p.slope_vec && nn < p.coutT) ? p.slope_vec[co] : p.slope);
+            for (int i = 0; i < 8; ++i) {
+                const int nc = (n + i < p.coutT) ? n + i : 0;
+                co8[i] = (p.phases > 1) ? nc % p.cout : nc;
+                bv8[i] = 0.0f;
+                sv8[i] = p.slope;
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bv8[i] = p.bias[co8[i]];
+            }
+            if (p.slope_vec) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sv8[i] = p.slope_vec[co8[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool okc = n + i < p.coutT;
+                f[i] = conv_finish(p, f[i], okc ? bv8[i] : 0.0f, ga, okc ? sv8[i] : p.slope);
+            }
         }
         if (p.out_layout == VT_OUT_NHWC) {
             store_nhwc8(p, m, n, f);
@@ -1439,9 +1465,14 @@ conv_splitk_reduce_stats_kernel(const ConvArgs p, int chunk_px, int chunks, int 
     if (cv < cvn) {
         float bv[VEC], sv[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            bv[i] = p.bias ? p.bias[n + i] : 0.0f;
-            sv[i] = p.slope_vec ? p.slope_vec[n + i] : p.slope;
+        for (int i = 0; i < VEC; ++i) bv[i] = 0.0f, sv[i] = p.slope;
+        if (p.bias) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) bv[i] = p.bias[n + i];
+        }
+        if (p.slope_vec) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) sv[i] = p.slope_vec[n + i];
         }
         for (int px = p_lo + prow; px < p_hi; px += ROWS) {
             const int64_t m = (int64_t)img * hw + px;
