@@ -211,7 +211,8 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
                     const u64v rv = *reinterpret_cast<const u64v*>(rec + (size_t)t * p.cin * 2);
                     mv[k] = vt_u2f(rv.x);
                     qv[k] = vt_u2f(rv.y);
-                    cv[k] = (t0 + k < nt) ? cnt[t] : 0.0f;
+                    const float cload = cnt[t];                // unconditional (t is clamped): `cond ? cnt[t] : 0` is a branch
+                    cv[k] = (t0 + k < nt) ? cload : 0.0f;       // + a dependent round trip per record
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
