@@ -351,3 +351,62 @@ def test_frame_path_never_reads_the_entries_the_broadcast_skips(dev, tag):
     lean = VToonifyEngine({k: (torch.zeros_like(v) if frames.inference_unused(k) else v).to(dev) for k, v in sd.items()},
                           BB[tag], 256, dt, dev)
     assert torch.equal(lean.forward(x, s, 0.5), y0) and torch.equal(lean.map_style(s), w0)
+
+
+def test_engine_housekeeping_round3(dev, monkeypatch):
+    """Round-3 call-path changes: the frame is read in place (fp32 / bf16 / fp16 contiguous) or staged (anything else),
+    style rows and d_s are uploaded only when they change, borrow=True hands out the plan's own buffer, the plan cache
+    is an LRU (VT_MAX_PLANS), and the drop-in module's precision follows VTOONIFY_AMD_DTYPE / compute_dtype with a
+    fingerprint over EVERY parameter."""
+    sd = synth.synth_state_dict(load_keys("T"), 0)
+    dt = torch.bfloat16 if dev.type == "cpu" else torch.float32
+    monkeypatch.setenv("VT_MAX_PLANS", "2")
+    eng = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, "toonify", 256, dt, dev)
+    assert eng.max_plans == 2
+    x = synth.synth_frames(1, 16, 16, seed=4).to(dev)
+    s = synth.synth_style(seed=6).to(dev)
+    y0 = eng.forward(x, s, 0.5)
+    # non-contiguous view and fp64 input go through the staging copy, fp16 / bf16 are read in place: the layout kernel
+    # rounds to the compute dtype either way
+    xt = x.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    assert not xt.is_contiguous() and torch.equal(eng.forward(xt, s, 0.5), y0)
+    assert torch.equal(eng.forward(x.double(), s, 0.5), y0)
+    xh = x.to(torch.bfloat16)
+    assert torch.equal(eng.forward(xh, s, 0.5), eng.forward(xh.float(), s, 0.5))
+    # the upload of style rows is skipped for the same tensor + version, repeated after an in-place edit
+    plan = eng.plan_for(1, 16, 16, True, False)
+    assert plan.up_ref is s and torch.equal(eng.forward(x, s, 0.5), y0)
+    s2 = s.clone()
+    s2.mul_(1.5)
+    y2 = eng.forward(x, s2, 0.5)
+    assert not torch.equal(y2, y0) and plan.up_ref is s2
+    s2.mul_(1.0 / 1.5)                      # same object, new version: must be uploaded again
+    assert torch.allclose(eng.forward(x, s2, 0.5).float(), y0.float(), rtol=0, atol=2e-2 * float(y0.float().abs().max()))
+    # borrow: the plan's buffer itself, overwritten by the next call on the lane
+    yb = eng.forward(x, s, 0.5, borrow=True)
+    assert yb.data_ptr() == plan.image.data_ptr() and torch.equal(yb, y0)
+    eng.forward(x.flip(3).contiguous(), s, 0.5, borrow=True)
+    assert not torch.equal(yb, y0)          # (the view now shows the next frame)
+    # LRU: a third shape evicts the least recently used plan
+    eng.forward(synth.synth_frames(1, 8, 16, seed=1).to(dev), s, 0.5)
+    eng.forward(synth.synth_frames(1, 8, 8, seed=1).to(dev), s, 0.5)
+    assert len(eng._plans) == 2 and not any(k[1:3] == (16, 16) for k in eng._plans)
+    assert torch.equal(eng.forward(x, s, 0.5), y0)      # rebuilt on demand
+    # ---- the module: precision switch + fingerprint
+    monkeypatch.delenv("VTOONIFY_AMD_DTYPE", raising=False)
+    assert VToonify(backbone="toonify").compute_dtype == torch.float32
+    monkeypatch.setenv("VTOONIFY_AMD_DTYPE", "bf16")
+    assert VToonify(backbone="toonify").compute_dtype == torch.bfloat16
+    assert VToonify(backbone="toonify", compute_dtype=torch.float32).compute_dtype == torch.float32
+    monkeypatch.setenv("VTOONIFY_AMD_DTYPE", "fp8")
+    with pytest.raises(ValueError):
+        VToonify(backbone="toonify")
+    monkeypatch.setenv("VTOONIFY_AMD_DTYPE", "bf16")
+    m = VToonify(backbone="toonify")
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    e0 = m.engine()
+    assert m.engine() is e0
+    with torch.no_grad():
+        m.fusion_skip[0].bias.add_(0.25)    # an in-place edit of a parameter that is neither first, middle nor last
+    assert m.engine() is not e0
