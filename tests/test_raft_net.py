@@ -180,6 +180,15 @@ def test_video_size_pair_is_finite_and_deterministic():
     f1 = flow_fn(Is[1:2].repeat(3, 1, 1, 1), Is)
     assert tuple(f1.shape) == (3, 2, 512, 512) and bool(torch.isfinite(f1).all())
     assert torch.equal(f1, flow_fn(Is[1:2].repeat(3, 1, 1, 1), Is))
+    # the opt-in hipGraph replay (VT_RAFT_GRAPH=1, captured on the second call of a shape) issues the same launches
+    import os
+    os.environ["VT_RAFT_GRAPH"] = "1"
+    try:
+        for _ in range(3):
+            assert torch.equal(f1, flow_fn(Is[1:2].repeat(3, 1, 1, 1), Is))
+        assert any(isinstance(v, tuple) for v in m.engine()._graphs.values())
+    finally:
+        os.environ["VT_RAFT_GRAPH"] = "0"
     y = smooth.smooth_parsing_maps(Is, Ps, flow_fn, w)
     assert tuple(y.shape) == (3, 19, 256, 256) and bool(torch.isfinite(y).all())
     # ---- at the WORKING size and iteration count against the CPU oracle (a restatement of raft.py:86-144 pinned to

@@ -23,10 +23,14 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the convolutions (correlation lookup, GRU state exchange and flow stay fp32)")
+    ap.add_argument("--pairs", type=int, default=0, help="frame pairs per call (default: the whole window, 2*window+1)")
     a = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
-    m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
+    m = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False),
+             compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     m.load_state_dict(synth.synth_state_dict({k: tuple(v) for k, v in raft_schema().items()}, 0))
     m = m.to(dev).eval()
     wn, S = 2 * a.window + 1, a.size
@@ -46,6 +50,14 @@ def main():
     f = flow()
     fuse(f)
     torch.cuda.synchronize()
+    if a.dtype != "fp32":   # deviation of the reduced-precision flow from the fp32 one on the same weights / frames
+        m32 = RAFT(argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False))
+        m32.load_state_dict(m.state_dict())
+        m32 = m32.to(dev).eval()
+        f32 = m32((image1 + 1) * 255.0 / 2, (Is + 1) * 255.0 / 2, iters=a.iters, test_mode=True)[1]
+        print(f"flow_up {a.dtype} vs fp32: max |d| {float((f - f32).abs().max()):.4f} px, mean |d| "
+              f"{float((f - f32).abs().mean()):.5f} px, max |flow| {float(f32.abs().max()):.2f} px")
+        del m32
     tf, tu = [], []
     for _ in range(a.reps):
         t0 = time.perf_counter()
@@ -60,7 +72,7 @@ def main():
     tf.sort()
     tu.sort()
     print(f"RAFT {wn} pairs {S}x{S}, {a.iters} iterations: {1e3 * tf[len(tf) // 2]:.1f} ms "
-          f"({1e3 * tf[len(tf) // 2] / wn:.2f} ms per pair, eager fp32); warp + fusion + Downsample of the window: "
+          f"({1e3 * tf[len(tf) // 2] / wn:.2f} ms per pair, {a.dtype}, hipGraph replay {os.environ.get('VT_RAFT_GRAPH', '0') == '1'}); warp + fusion + Downsample of the window: "
           f"{1e3 * tu[len(tu) // 2]:.2f} ms; output {tuple(y.shape)}, finite {bool(torch.isfinite(y).all())}")
 
 

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -175,6 +176,7 @@ class RaftEngine:
         self.w: Dict[str, torch.Tensor] = {}
         self.b: Dict[str, torch.Tensor] = {}
         self.keep_taps = False      # tests: keep intermediate tensors of the first iteration in self.taps
+        self._graphs = {}           # (shape, iters) -> "seen" | (hipGraph, static inputs, outputs)
 
         def add(name, key, bn=None, cin_dst=None, chan_map=None, rows=None):
             w, b = f32(key + ".weight"), f32(key + ".bias")
@@ -301,7 +303,42 @@ class RaftEngine:
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, iters: int = 12, flow_init=None,
                 all_predictions: bool = False):
         """image1, image2 (N,3,H,W) in [0,255], H and W multiples of 8 (InputPadder of the caller).  Returns
-        (flow_low (N,2,H/8,W/8), [flow_up (N,2,H,W)] -- every iteration's when all_predictions, else the last)."""
+        (flow_low (N,2,H/8,W/8), [flow_up (N,2,H,W)] -- every iteration's when all_predictions, else the last).
+
+        VT_RAFT_GRAPH=1: the inference form (test_mode: no flow_init, last prediction only) as ONE hipGraph replay per
+        (N, H, W, iters), captured on the second call of a shape; bit-identical to the eager launches.  OFF by default:
+        measured (round 3, profiles/r03_raft_bench.txt) it changes nothing -- 116.5 vs 117.1 ms for 11 pairs of 512x512 x 20
+        iterations, 29.0 vs 29.2 ms for one pair: the ~1 300 launches are GPU-bound (fp32 convolutions on 64x64-pixel
+        maps: tiny grids), not host-bound.  What does move it is the arithmetic: RAFT(..., compute_dtype=torch.bfloat16)
+        runs the same window in 62.6 ms (5.7 ms per pair); its deviation from the fp32 flow cannot be judged on synthetic
+        weights (they produce 600-pixel flows), so fp32 stays the default."""
+        if (self.device.type == "cuda" and flow_init is None and not all_predictions and not self.keep_taps and
+                os.environ.get("VT_RAFT_GRAPH", "0") == "1" and image1.shape == image2.shape and image1.ndim == 4):
+            key = (tuple(image1.shape), int(iters))
+            ent = self._graphs.get(key)
+            if ent is None:
+                self._graphs[key] = "seen"          # first call of a shape: eager (also the warm-up of the capture)
+            else:
+                if ent == "seen":
+                    if len(self._graphs) > 8:
+                        self._graphs.clear()
+                    i1 = torch.empty(image1.shape, dtype=torch.float32, device=self.device)
+                    i2 = torch.empty_like(i1)
+                    i1.copy_(image1)
+                    i2.copy_(image2)
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        lo, ups = self._forward(i1, i2, iters, None, False)
+                    ent = self._graphs[key] = (g, i1, i2, lo, ups[-1])
+                g, i1, i2, lo, up = ent
+                i1.copy_(image1)
+                i2.copy_(image2)
+                g.replay()
+                return lo.clone(), [up.clone()]
+        return self._forward(image1, image2, iters, flow_init, all_predictions)
+
+    def _forward(self, image1, image2, iters, flow_init, all_predictions):
         self.lib = _lib.lib()
         if image1.shape != image2.shape or image1.ndim != 4 or image1.shape[1] != 3:
             raise _lib.VtError("RAFT: image1 / image2 must be (N,3,H,W) of the same shape")
