@@ -523,17 +523,33 @@ def main():
         assert torch.equal(ym, eng.forward(pool[(nwarm - 1) % len(pool)], style, d_s, shared_style=True,
                                            use_graph=use_graph, lane=0))
         n1 = min(args.steps, 1 if emu else 50)
-        ts = []
-        for _ in range(reps):
-            t1 = time.perf_counter()
-            for i in range(n1):
-                m(pool[i % len(pool)], sw, d_s=d_s)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        t1 = sorted(ts)[len(ts) // 2]
+
+        def time_module():
+            ts = []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                for i in range(n1):   # a NEW style tensor per call, as style_transfer.py:176 writes it
+                    m(pool[i % len(pool)], style.repeat(B, 1, 1), d_s=d_s)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return sorted(ts)[len(ts) // 2]
+        t1 = time_module()
         module_call = {"value": n1 * B / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1e3 * t1 / n1,
                        "what": f"VToonify.__call__(x, s_w.repeat(B,1,1), d_s=...) of the drop-in module, B = {B}, one call in "
-                               f"flight, output copied out of the plan like a fresh tensor"}
+                               f"flight, output copied out of the plan like a fresh tensor; the module's style gate is on "
+                               f"(the style path is skipped on the device while the style rows and d_s do not change -- "
+                               f"bit-identical outputs)"}
+        # the same module with the gate off: the style path recomputed on every call, like `value`
+        os.environ["VT_STYLE_GATE"] = "0"
+        m.invalidate()
+        for i in range(nwarm):
+            ym2 = m(pool[i % len(pool)], sw, d_s=d_s)
+        torch.cuda.synchronize()
+        assert torch.equal(ym2, ym)
+        t2 = time_module()
+        os.environ.pop("VT_STYLE_GATE", None)
+        module_call["recompute"] = {"value": n1 * B / t2, "ms_per_step": 1e3 * t2 / n1,
+                                    "what": "VT_STYLE_GATE=0: style path recomputed on every call"}
         del m
 
     result = None

@@ -269,6 +269,18 @@ int vt_modulate_weight_batch(const vt_modulate_item* items, int n_items, int out
 /* PixelNorm (model/stylegan/model.py:17-18) on (rows, dim) fp32. */
 int vt_pixel_norm(float* y, const float* x, int rows, int dim, vt_stream stream);
 
+/* Style gate (ABI 4).  The style path of VToonify.forward (model/vtoonify.py:212-224; model/stylegan/model.py:259-267)
+ * depends only on (W+ rows, d_s), which the video loop keeps for every frame but re-materialises per call
+ * (`s_w.repeat(B,1,1)`, style_transfer.py:176).  vt_style_gate compares `fresh` with `cached` (n fp32 words, bitwise) on
+ * the device -- no host synchronisation: flag[0] <- 1 and cached <- fresh when they differ or flag[1] (the host's "force"
+ * word: new plan, another d_s) is set, else flag[0] <- 0; flag[1] <- 0.  The *_gated forms of the three style launches
+ * take that flag word and return immediately when it is 0 (gate == NULL: always run). */
+int vt_style_gate(int* flag, float* cached, const float* fresh, int n, vt_stream stream);
+int vt_linear_batch_gated(const vt_linear_item* items, int n_items, const int* gate, vt_stream stream);
+int vt_modulate_weight_batch_gated(const vt_modulate_item* items, int n_items, int out_dtype, const int* gate,
+                                   vt_stream stream);
+int vt_pixel_norm_gated(float* y, const float* x, int rows, int dim, const int* gate, vt_stream stream);
+
 /* ---------------------------------------------------------------------------------
  * InstanceNorm / AdaIN (model/dualstylegan.py:6-21) on NHWC activations.
  * vt_instnorm_stats accumulates deterministic per-chunk (count, mean, M2) partials and

@@ -410,3 +410,38 @@ def test_engine_housekeeping_round3(dev, monkeypatch):
     with torch.no_grad():
         m.fusion_skip[0].bias.add_(0.25)    # an in-place edit of a parameter that is neither first, middle nor last
     assert m.engine() is not e0
+
+
+def test_style_gate_is_transparent(dev):
+    """VToonifyEngine(style_gate=True) (what the drop-in module uses): the style path is skipped ON THE DEVICE when a call's
+    W+ rows and d_s equal the ones its products were computed from -- the video loop's `s_w.repeat(B,1,1)` is a new tensor
+    with the same content on every call (style_transfer.py:176).  Outputs are bit-identical to recomputing; a changed
+    row, a changed d_s (D) and a return to an earlier style all recompute."""
+    lean = dev.type == "cpu"
+    tag = "T" if lean else "D"
+    sd = {k: v.to(dev) for k, v in synth.synth_state_dict(load_keys(tag), 0).items()}
+    dt = torch.bfloat16
+    ref = VToonifyEngine(sd, BB[tag], 256, dt, dev)
+    eng = VToonifyEngine(sd, BB[tag], 256, dt, dev, style_gate=True)
+    x = synth.synth_frames(2, 16, 16, seed=4).to(dev)
+    s = synth.synth_style(seed=6).to(dev)
+    y0 = ref.forward(x, s.repeat(2, 1, 1), 0.5)
+    flag = lambda: eng.plan_for(2, 16, 16, True, not lean).bufs["style_gate"].cpu().tolist()
+    for i in range(3):
+        assert torch.equal(eng.forward(x, s.repeat(2, 1, 1), 0.5), y0), i     # a NEW tensor object every call
+        assert flag() == [1 if i == 0 else 0, 0], (i, flag())                   # computed once, then skipped
+    s2 = s + 0.125
+    y2 = ref.forward(x, s2.repeat(2, 1, 1), 0.5)
+    assert not torch.equal(y2, y0)
+    assert torch.equal(eng.forward(x, s2.repeat(2, 1, 1), 0.5), y2) and flag()[0] == 1
+    assert torch.equal(eng.forward(x, s2.repeat(2, 1, 1), 0.5), y2) and flag()[0] == 0
+    assert torch.equal(eng.forward(x, s.repeat(2, 1, 1), 0.5), y0) and flag()[0] == 1
+    if not lean:   # the style degree is part of the gate (VToonify-D; T ignores it)
+        y3 = ref.forward(x, s.repeat(2, 1, 1), 0.75)
+        assert not torch.equal(y3, y0)
+        assert torch.equal(eng.forward(x, s.repeat(2, 1, 1), 0.75), y3) and flag()[0] == 1
+        assert torch.equal(eng.forward(x, s.repeat(2, 1, 1), 0.75), y3) and flag()[0] == 0
+    # W-space styles (model/vtoonify.py:212-215) go through the same gate
+    yw = ref.forward(x, s[:, 3].repeat(2, 1), 0.5)
+    assert torch.equal(eng.forward(x, s[:, 3].repeat(2, 1), 0.5), yw)
+    assert torch.equal(eng.forward(x, s[:, 3].repeat(2, 1), 0.5), yw) and flag()[0] == 0

@@ -97,6 +97,10 @@ _SIGS = {
     "vt_linear_batch": (C.c_int, [C.POINTER(LinearItem), C.c_int, C.c_void_p]),
     "vt_modulate_weight_batch": (C.c_int, [C.POINTER(ModulateItem), C.c_int, C.c_int, C.c_void_p]),
     "vt_pixel_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vt_style_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vt_linear_batch_gated": (C.c_int, [C.POINTER(LinearItem), C.c_int, C.c_void_p, C.c_void_p]),
+    "vt_modulate_weight_batch_gated": (C.c_int, [C.POINTER(ModulateItem), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vt_pixel_norm_gated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vt_instnorm_ws_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "vt_instnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

@@ -42,7 +42,8 @@ linear_kernel(float* __restrict__ y, int ld_y, const float* __restrict__ x, int 
 }
 
 __global__ void __launch_bounds__(256)
-pixel_norm_kernel(float* __restrict__ y, const float* __restrict__ x, int rows, int dim) {
+pixel_norm_kernel(float* __restrict__ y, const float* __restrict__ x, int rows, int dim, const int* __restrict__ gate) {
+    if (gate && gate[0] == 0) return;   // style gate: the inputs of the style path did not change (vt_style_gate)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r = wave < rows ? wave : rows - 1;
@@ -140,6 +141,7 @@ constexpr int LIN_BATCH = 24, MOD_BATCH = 16;
 
 struct LinearTable {
     vt_linear_item it[LIN_BATCH];
+    const int* gate;   // NULL, or the style gate's flag: 0 = the whole launch is skipped
     int32_t first_wave[LIN_BATCH + 1];
     int32_t n;
 };
@@ -151,6 +153,7 @@ struct LinearTable {
 // (Measured and dropped, round 2: FOUR output columns per wavefront -- a quarter of the waves, four weight rows in
 //  flight per lane -- is 2x slower: 52 + 45 + 20 us against 18 + 17 + 25 us for the three launches of a frame.)
 __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) {
+    if (t.gate && t.gate[0] == 0) return;
     constexpr int RB = 6;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -230,6 +233,7 @@ __global__ void __launch_bounds__(256) linear_batch_kernel(const LinearTable t) 
 
 struct ModTable {
     vt_modulate_item it[MOD_BATCH];
+    const int* gate;   // NULL, or the style gate's flag
     int32_t first_row[MOD_BATCH + 1];  // prefix of cout
     int32_t n;
 };
@@ -238,6 +242,7 @@ struct ModTable {
 // by the four waves through LDS in a fixed order, then all 256 lanes write the packed row(s).
 template <typename T>
 __global__ void __launch_bounds__(256) modulate_batch_kernel(const ModTable t) {
+    if (t.gate && t.gate[0] == 0) return;
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int lo = 0, hi = t.n;  // binary search of the row prefix (scalar loads, <= 4 steps)
@@ -355,7 +360,7 @@ extern "C" int vt_linear(float* y, int ld_y, const float* x, int ld_x, const flo
 extern "C" int vt_pixel_norm(float* y, const float* x, int rows, int dim, vt_stream stream) {
     VT_REQUIRE(y && x && rows >= 0 && dim > 0, "vt_pixel_norm: bad arguments");
     if (rows == 0) return VT_OK;
-    VT_LAUNCH(pixel_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, x, rows, dim);
+    VT_LAUNCH(pixel_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, x, rows, dim, (const int*)nullptr);
     return vt_check_launch("vt_pixel_norm");
 }
 
@@ -401,11 +406,19 @@ extern "C" int vt_pack_conv_weight(void* out, const float* w, int cout, int cin_
     return vt_check_launch("vt_pack_conv_weight");
 }
 
+static int linear_batch_impl(const vt_linear_item* items, int n_items, const int* gate, vt_stream stream);
 extern "C" int vt_linear_batch(const vt_linear_item* items, int n_items, vt_stream stream) {
+    return linear_batch_impl(items, n_items, nullptr, stream);
+}
+extern "C" int vt_linear_batch_gated(const vt_linear_item* items, int n_items, const int* gate, vt_stream stream) {
+    return linear_batch_impl(items, n_items, gate, stream);
+}
+static int linear_batch_impl(const vt_linear_item* items, int n_items, const int* gate, vt_stream stream) {
     VT_REQUIRE(items && n_items >= 0, "vt_linear_batch: bad arguments");
     for (int base = 0; base < n_items; base += LIN_BATCH) {
         LinearTable t;
         memset(&t, 0, sizeof(t));
+        t.gate = gate;
         t.n = (n_items - base < LIN_BATCH) ? n_items - base : LIN_BATCH;
         int64_t waves = 0;
         for (int i = 0; i < t.n; ++i) {
@@ -428,13 +441,22 @@ extern "C" int vt_linear_batch(const vt_linear_item* items, int n_items, vt_stre
     return VT_OK;
 }
 
+static int modulate_batch_impl(const vt_modulate_item* items, int n_items, int out_dtype, const int* gate, vt_stream stream);
 extern "C" int vt_modulate_weight_batch(const vt_modulate_item* items, int n_items, int out_dtype,
                                         vt_stream stream) {
+    return modulate_batch_impl(items, n_items, out_dtype, nullptr, stream);
+}
+extern "C" int vt_modulate_weight_batch_gated(const vt_modulate_item* items, int n_items, int out_dtype, const int* gate,
+                                              vt_stream stream) {
+    return modulate_batch_impl(items, n_items, out_dtype, gate, stream);
+}
+static int modulate_batch_impl(const vt_modulate_item* items, int n_items, int out_dtype, const int* gate, vt_stream stream) {
     VT_REQUIRE(items && n_items >= 0, "vt_modulate_weight_batch: bad arguments");
     VT_REQUIRE(out_dtype == VT_F32 || out_dtype == VT_BF16, "vt_modulate_weight_batch: unsupported dtype %d", out_dtype);
     for (int base = 0; base < n_items; base += MOD_BATCH) {
         ModTable t;
         memset(&t, 0, sizeof(t));
+        t.gate = gate;
         t.n = (n_items - base < MOD_BATCH) ? n_items - base : MOD_BATCH;
         int64_t rows = 0;
         for (int i = 0; i < t.n; ++i) {
@@ -459,4 +481,47 @@ extern "C" int vt_modulate_weight_batch(const vt_modulate_item* items, int n_ite
         if (rc) return rc;
     }
     return VT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------
+// Style gate (round 3): the style path (mapping linears, modulation + demodulation of 15 conv weights, AdaIN gamma /
+// beta) depends only on (W+ rows, d_s), which a video keeps for all of its frames (style_transfer.py:138-150,176 passes
+// `s_w.repeat(B,1,1)` -- a NEW tensor with the same content -- on every call).  vt_style_gate compares the caller's rows
+// with the ones the plan's style products were computed from, ON THE DEVICE (no host sync): flag[0] = 1 and the rows are
+// adopted when anything differs (or flag[1], the host's "force" word, is set: a new plan, another d_s), else flag[0] = 0
+// and the *_gated launches of the style path return at once.  Bitwise comparison: -0.0 vs 0.0 or a NaN payload count as
+// a change, which only costs a recomputation.
+// ---------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) style_gate_kernel(int* __restrict__ flag, uint32_t* __restrict__ cached,
+                                                          const uint32_t* __restrict__ fresh, int n) {
+    __shared__ int diff;
+    if (threadIdx.x == 0) diff = flag[1];
+    __syncthreads();
+    int d = 0;
+    for (int i = threadIdx.x; i < n; i += 256) d |= (cached[i] != fresh[i]) ? 1 : 0;
+    if (d) diff = 1;   // benign race: every writer stores 1
+    __syncthreads();
+    const int changed = diff;
+    if (changed) {
+        for (int i = threadIdx.x; i < n; i += 256) cached[i] = fresh[i];
+    }
+    if (threadIdx.x == 0) {
+        flag[0] = changed;
+        flag[1] = 0;
+    }
+}
+}  // namespace
+
+extern "C" int vt_style_gate(int* flag, float* cached, const float* fresh, int n, vt_stream stream) {
+    VT_REQUIRE(flag && cached && fresh && n > 0, "vt_style_gate: bad arguments");
+    VT_LAUNCH(style_gate_kernel, dim3(1), dim3(256), stream, flag, (uint32_t*)cached, (const uint32_t*)fresh, n);
+    return vt_check_launch("vt_style_gate");
+}
+
+extern "C" int vt_pixel_norm_gated(float* y, const float* x, int rows, int dim, const int* gate, vt_stream stream) {
+    VT_REQUIRE(y && x && rows > 0 && dim > 0, "vt_pixel_norm: bad arguments");
+    VT_LAUNCH(pixel_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, x, rows, dim, gate);
+    return vt_check_launch("vt_pixel_norm");
 }

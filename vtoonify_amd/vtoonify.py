@@ -252,8 +252,11 @@ class VToonify(nn.Module):
             self._engine = None
         if self._engine is None:
             dev = next(self.parameters()).device
+            # style_gate: a video passes the same style rows on every call (as a new tensor: s_w.repeat(B,1,1),
+            # style_transfer.py:176); the style path is then skipped on the device, bit-identical to recomputing it
             self._engine = VToonifyEngine(self.state_dict(), self.backbone, self.in_size,
-                                          self.compute_dtype, dev)
+                                          self.compute_dtype, dev,
+                                          style_gate=os.environ.get("VT_STYLE_GATE", "1") != "0")
             self._engine_probe = self._probe()
         return self._engine
 
