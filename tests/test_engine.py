@@ -429,7 +429,9 @@ def test_style_gate_is_transparent(dev):
     flag = lambda: eng.plan_for(2, 16, 16, True, not lean).bufs["style_gate"].cpu().tolist()
     for i in range(3):
         assert torch.equal(eng.forward(x, s.repeat(2, 1, 1), 0.5), y0), i     # a NEW tensor object every call
-        assert flag() == [1 if i == 0 else 0, 0], (i, flag())                   # computed once, then skipped
+        # computed once, then skipped (on a GPU the first call is a warm-up launch + the capture's replay: the replay
+        # already finds the rows unchanged)
+        assert flag() == [1 if (i == 0 and lean) else 0, 0], (i, flag())
     s2 = s + 0.125
     y2 = ref.forward(x, s2.repeat(2, 1, 1), 0.5)
     assert not torch.equal(y2, y0)
