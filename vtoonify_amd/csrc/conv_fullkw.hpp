@@ -77,6 +77,11 @@ __device__ __forceinline__ void fkw_mma(f32x4 (&acc)[2][2], const u128 (&wr)[18]
     };
     read_a(fa[LO & 1], LO);
     if constexpr (ABL == 35) read_a(fa[(LO + 1) & 1], LO + 1);   // ablation: MFMAs on two resident fragment pairs, no further LDS reads
+    // The interleave is PINNED (sched_group_barrier): the two fragment reads of sub-step st+1, then the four MFMAs of
+    // sub-step st.  Left alone, hipcc (241 registers in use) re-used ONE fragment register quad and emitted
+    // ds_read -> lgkmcnt(0) -> 2 MFMAs, 36 times per step: every MFMA pair behind a fresh LDS round trip.
+    constexpr bool PIN = !FIRST && ABL == 0;
+    if constexpr (PIN) vt_sched_group<0x100, 2>();
 #pragma unroll
     for (int st = LO; st < HI; ++st) {
         if constexpr (FIRST) fkw_wait_pairs<17>(17 - st);
@@ -89,6 +94,10 @@ __device__ __forceinline__ void fkw_mma(f32x4 (&acc)[2][2], const u128 (&wr)[18]
             }
             Mma<T>::run(acc[a][0], wr[st][0], fa[st & 1][a]);
             Mma<T>::run(acc[a][1], wr[st][1], fa[st & 1][a]);
+        }
+        if constexpr (PIN) {
+            if (st + 1 < HI) vt_sched_group<0x100, 2>();
+            vt_sched_group<0x008, 4>();
         }
     }
 }

@@ -224,7 +224,13 @@ __device__ __forceinline__ void vt_ticket_store(int* p, int v) {
 
 #ifdef VT_EMU
 static inline void vt_sched_fence() {}
+template <int MASK, int N>
+static inline void vt_sched_group() {}
 #else
+// scheduling group: the next N instructions of class MASK (0x008 MFMA, 0x100 LDS read, 0x200 LDS write, 0x020 VMEM
+// read, 0x002 VALU) come next in the region's schedule -- a sequence of these pins the interleave of an unrolled loop
+template <int MASK, int N>
+__device__ __forceinline__ void vt_sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }
 // scheduling fence: the compiler may not move instructions across it
 __device__ __forceinline__ void vt_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
