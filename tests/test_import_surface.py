@@ -75,11 +75,12 @@ assert tuple(y.shape) == (2, 3, 64, 64) and bool(torch.isfinite(y).all())
 # the drop-in computes in the REFERENCE'S precision unless told otherwise (fp32; bf16 is opt-in: VTOONIFY_AMD_DTYPE /
 # compute_dtype): the call above, made by the reference's own line, matches the CPU oracle to the fp32 bar
 assert vt.compute_dtype == torch.float32
-from oracle import vtoonify_oracle as O
-O.set_backend("torch")
-want = O.vtoonify_forward(synth.to_numpy_sd(sd), ns["inputs"].numpy(), ns["s_w"].repeat(2, 1, 1).numpy(), 0.5, BACKBONE)
-err = float((y.numpy() - want).__abs__().max() / abs(want).max())
-assert err <= 1e-4, err
+if BACKBONE == "toonify":   # (the D forward against the oracle is tests/test_engine.py::test_golden_fp32; once is enough here)
+    from oracle import vtoonify_oracle as O
+    O.set_backend("torch")
+    want = O.vtoonify_forward(synth.to_numpy_sd(sd), ns["inputs"].numpy(), ns["s_w"].repeat(2, 1, 1).numpy(), 0.5, BACKBONE)
+    err = float((y.numpy() - want).__abs__().max() / abs(want).max())
+    assert err <= 1e-4, err
 # the same frames through the engine API directly: the module call is the same computation
 if BACKBONE == "toonify":   # (an emulated D forward is ~10 s: once is enough)
     y2 = vt.engine().forward(ns["inputs"], ns["s_w"], 0.5)
