@@ -69,6 +69,8 @@ def main():
                     help="run the up-sampling convs (phases 4 rows) as conv_transpose2d + LDS blur (vt_conv_desc.up_fir)")
     ap.add_argument("--stream", action="store_true",
                     help="attach the fragment-stream weights (whole-K kernel where eligible; add --hint 400000000 to force it)")
+    ap.add_argument("--adain", type=int, default=0,
+                    help="whole-K trunk convs: bit 0 = AdaIN consumer (in_tile_stats + in_gb), bit 1 = emit tile_stats, bit 2 = residual")
     ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
     args = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
@@ -117,6 +119,27 @@ def main():
             rgbo = torch.randn(n, 3, ho, wo, device=dev)
             d.rgb_weight, d.rgb_bias = rgbw.data_ptr(), rgbb.data_ptr()
             d.rgb_resid = d.rgb_out = rgbo.data_ptr()
+        keep = []
+        if args.adain and name.startswith(("res", "modres")):
+            nb = K.conv_tile_stats_bytes(n, h, w, dil, cout) // 4
+            if args.adain & 1:   # records of a producer with dilation 1 over the same tensor
+                prod = torch.zeros(K.conv_tile_stats_bytes(n, h, w, 1, cin) // 4, device=dev)
+                dp = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=h, w=w, out_h=ho, out_w=wo, weight=wt, cout=cout, kh=k,
+                                      kw=k, pad=1, bias=bias, act=K.ACT_LRELU, dtype=K.dt_code(dt), out=x.clone(), ld_out=cout,
+                                      tile_stats=prod)
+                dp.weight_stream = wst.data_ptr()
+                _lib.check(lib.vt_conv2d(C.byref(dp), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "producer")
+                gb = torch.randn(n, 2 * cin, device=dev)
+                d.in_tile_stats, d.in_stats_dil, d.in_gb, d.in_ld_gb = prod.data_ptr(), 1, gb.data_ptr(), 2 * cin
+                keep += [prod, gb]
+            if args.adain & 2:
+                ts = torch.zeros(nb, device=dev)
+                d.tile_stats = ts.data_ptr()
+                keep.append(ts)
+            if args.adain & 4:
+                rs = torch.randn(n, ho, wo, cout, device=dev).to(dt)
+                d.resid, d.ld_res, d.beta = rs.data_ptr(), cout, 1.0
+                keep.append(rs)
         if not args.nosplit:
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         tile = lib.vt_conv2d_tile(C.byref(d))

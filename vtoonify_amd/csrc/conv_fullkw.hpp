@@ -244,7 +244,10 @@ conv_fullkw_kernel(const ConvArgs p, const FullkwArgs g) {
 
     // AdaIN prologue (model/dualstylegan.py:16-21), conv_fullk_kernel's merge verbatim: one image per workgroup, so
     // scale / shift are computed once (lane = channel) and parked in the wave's table
-    if (p.in_tile_stats) {
+    if (p.in_tile_stats && ABL == 45) {   // ablation: no merge, identity table
+        if (lane < BK) tab[lane] = 1.0f, tab[BK + lane] = 0.0f;
+        vt_wave_sync();
+    } else if (p.in_tile_stats) {
         const int cl = lane & (BK - 1);
         const int d2 = p.in_stats_dil;
         const int nt = d2 * d2 * vt_cdiv_dev(vt_cdiv_dev(p.H, d2), FK_TH) * vt_cdiv_dev(vt_cdiv_dev(p.W, d2), FK_TW);
@@ -421,7 +424,7 @@ conv_fullkw_kernel(const ConvArgs p, const FullkwArgs g) {
                 live_st = live;
             }
         }
-        if (!p.tile_stats || !h) return;
+        if (!p.tile_stats || !h || ABL == 46) return;
         // ---- {mean, M2} record of the 8x8 tile whose second half just finished: two passes, lanes 8 apart hold the
         // 8 pixels of one tile row, the 8 wavefronts the 8 rows; fixed shuffle tree + wave order 0..7 ----
         const int tcount = fk_tile_count(t, d, g.tiles_y, g.tiles_x, p.H, p.W);
@@ -499,7 +502,7 @@ conv_fullkw_kernel(const ConvArgs p, const FullkwArgs g) {
     };
     if (SAFE) vt_vmcnt_fence<0>();
     else vt_vmcnt_fence<2 * NSUB + 8>();     // B, A, R0, patch 0 landed (36 weight loads + patch 1 may be in flight)
-    if (p.in_tile_stats) adain_rewrite(0);
+    if (p.in_tile_stats && ABL != 44) adain_rewrite(0);
     zero_acc();
     fkw_mma<T, true, 0, NSUB>(acc, wr, my, abase);
     vt_sched_fence();
@@ -511,7 +514,7 @@ conv_fullkw_kernel(const ConvArgs p, const FullkwArgs g) {
     for (int s = 1; s < nsteps; ++s) {
         const unsigned char* slot = my + (s & 1) * FW_SLOT;
         wait_patch(s);                       // patch s (and the residual of step s-1) landed
-        if (p.in_tile_stats) adain_rewrite(s);
+        if (p.in_tile_stats && ABL != 44) adain_rewrite(s);
         zero_acc();
         if constexpr (ABL != 31) fkw_mma<T, false, 0, 9, ABL>(acc, wr, slot, abase);
         if constexpr (ABL != 33) finish_step(s - 1);
@@ -616,7 +619,7 @@ int launch_fullkw(const ConvArgs& a, FullkwArgs g, int group, vt_stream stream) 
     }
     if (sizeof(T) == 2 && abl) {
         VT_FKW_ABL(31) VT_FKW_ABL(32) VT_FKW_ABL(33) VT_FKW_ABL(35) VT_FKW_ABL(36) VT_FKW_ABL(37) VT_FKW_ABL(38)
-        VT_FKW_ABL(41) VT_FKW_ABL(42) VT_FKW_ABL(43)
+        VT_FKW_ABL(41) VT_FKW_ABL(42) VT_FKW_ABL(43) VT_FKW_ABL(44) VT_FKW_ABL(45) VT_FKW_ABL(46)
     }
 #undef VT_FKW_ABL
     if (safe) {

@@ -529,6 +529,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         }
     }
     if (!rgbf) return;
+    // up-sampled skip + bias of the pixels this lane writes: ALL loads issued here, unconditional at clamped offsets under
+    // wave-uniform branches, so that they fly during the shuffles / the LDS exchange below.  (`if (p.rgb_resid) v +=
+    // p.rgb_resid[off]` per element was a branch + load + vmcnt(0) each: 3 x TM dependent HBM round trips at the end of
+    // every tile -- the 128 -> 128 @256^2 conv spent more time there than in its MFMA loop.)
+    const int HoWo = p.Ho * p.Wo;
+    const bool writer = wn == 0 && q == 0;
+    int64_t roff[TM];
+    float rsd[TM][3], rb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+        const int mc = m < 0 ? 0 : m;
+        const int img = mc / HoWo;
+        roff[a] = (m < 0 || !writer) ? (int64_t)-1 : (int64_t)img * 3 * HoWo + (mc - img * HoWo);
+    }
+    if (p.rgb_resid) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rsd[a][j] = p.rgb_resid[(roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo];
+    } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) rsd[a][0] = rsd[a][1] = rsd[a][2] = 0.0f;
+    }
+    if (p.rgb_bias) rb[0] = p.rgb_bias[0], rb[1] = p.rgb_bias[1], rb[2] = p.rgb_bias[2];
     // sum the partial dot products over the 4 lane groups (channels 4q..4q+3 of every fragment) ...
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -550,7 +575,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                 for (int j = 0; j < 3; ++j) xs[((wn * WM + wm) * (TM * 16) + a * 16 + l15) * 3 + j] = rp[a][j];
         }
         __syncthreads();
-        if (wn == 0 && q == 0) {
+        if (writer) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -561,22 +586,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                 }
         }
     }
-    if (wn == 0 && q == 0) {
-        const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
-            if (m < 0) continue;
-            const int img = m / HoWo;
-            const int rem = m - img * HoWo;
+    for (int a = 0; a < TM; ++a) {
+        if (roff[a] < 0) continue;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int64_t off = ((int64_t)img * 3 + j) * HoWo + rem;
-                float v = rp[a][j] + (p.rgb_bias ? p.rgb_bias[j] : 0.0f);
-                if (p.rgb_resid) v += p.rgb_resid[off];
-                p.rgb_out[off] = v;
-            }
-        }
+        for (int j = 0; j < 3; ++j) p.rgb_out[roff[a] + (int64_t)j * HoWo] = (rp[a][j] + rb[j]) + rsd[a][j];
     }
 }
 
