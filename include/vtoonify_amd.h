@@ -307,6 +307,12 @@ int vt_instnorm_apply(void* out, int ld_out, const void* x, int ld_x, int n, int
 int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
                             const float* style_gb, int ld_gb, const void* partials, int dtype,
                             vt_stream stream);
+/* AdaIN(x) of a small plane (hw <= 4096: the trunk of frames up to 512x512 inputs) in ONE launch, statistics
+ * included: one workgroup per (image, 16-byte channel vector) holds its slice in registers.  nn.InstanceNorm2d
+ * (biased variance, eps 1e-5) + the style affine (model/stylegan/dualstylegan.py:6-21).  `out` may alias `x`.
+ * VT_ERR_UNSUPPORTED for larger planes. */
+int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
+                      const float* style_gb, int ld_gb, int dtype, vt_stream stream);
 /* out[p][c] = x*scale+shift  (and the |x-other| half when absdiff_other != NULL). */
 int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
                     const void* absdiff_other, int ld_other, const float* scale,

@@ -689,6 +689,43 @@ def test_instnorm_adain_fusion_pack(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_instnorm_plane_one_launch(dev, dtype):
+    """vt_instnorm_plane: AdaIN of a small plane, statistics included, one launch (dualstylegan.py:6-21 -- biased variance,
+    eps 1e-5, style affine).  Every registers-per-thread instance (1 / 4 / 8 / 16 pixels per thread), ragged plane sizes,
+    in-place operation, no style, an image alone == the same image inside a batch (bit-exact), too-large planes refused."""
+    from vtoonify_amd import _lib
+    lib = _lib.lib()
+    g = np.random.default_rng(31)
+    code = K.dt_code(dtype)
+    for N, Cc, H, W in ((2, 16, 16, 16), (2, 24, 32, 32), (3, 16, 37, 29), (1, 8, 45, 50), (1, 16, 64, 64)):
+        hw = H * W
+        x = (g.standard_normal((N, Cc, H, W)) * 2 + 1).astype(np.float32)
+        gb = g.standard_normal((N, 2 * Cc)).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+        gbt = T(gb, dev)
+        out = torch.zeros_like(xt)
+        assert lib.vt_instnorm_plane(out.data_ptr(), Cc, xt.data_ptr(), Cc, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
+                                     K._stream(xt)) == 0, lib.vt_last_error()
+        ref = gb[:, :Cc].reshape(N, Cc, 1, 1) * O.instance_norm(xq) + gb[:, Cc:].reshape(N, Cc, 1, 1)
+        assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
+        inpl = xt.clone()                                       # out aliases x
+        assert lib.vt_instnorm_plane(inpl.data_ptr(), Cc, inpl.data_ptr(), Cc, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
+                                     K._stream(xt)) == 0
+        assert torch.equal(inpl, out)
+        one = torch.zeros_like(xt[-1:])                         # the last image alone
+        assert lib.vt_instnorm_plane(one.data_ptr(), Cc, xt[-1:].contiguous().data_ptr(), Cc, 1, hw, Cc,
+                                     gbt[-1:].contiguous().data_ptr(), 2 * Cc, code, K._stream(xt)) == 0
+        assert torch.equal(one[0], out[-1])
+        plain = torch.zeros_like(xt)                            # no style: InstanceNorm2d alone
+        assert lib.vt_instnorm_plane(plain.data_ptr(), Cc, xt.data_ptr(), Cc, N, hw, Cc, None, 0, code, K._stream(xt)) == 0
+        assert rel_err(plain.float().cpu().permute(0, 3, 1, 2).numpy(), O.instance_norm(xq)) < \
+            (F32_TOL if dtype == torch.float32 else 8e-3)
+    big = torch.zeros((1, 65, 64, 8), dtype=dtype, device=dev)
+    assert lib.vt_instnorm_plane(big.data_ptr(), 8, big.data_ptr(), 8, 1, 65 * 64, 8, None, 0, code, K._stream(big)) == 2   # VT_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_patch_small_tile_whole_k(dev, dtype):
     """64-pixel x 64-channel patch instances (VT_FULLK plans): whole K range in one workgroup, or a
     few slices, for dilation 1 / 2 / 4; several channel chunks per workgroup (patch double buffer)."""

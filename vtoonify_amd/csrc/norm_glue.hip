@@ -252,6 +252,104 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
     }
 }
 
+// AdaIN of a SMALL plane in ONE launch, statistics included (the 32x32-pixel trunk, 12 per frame).  One workgroup per
+// (image, 16-byte channel vector): its slice of the plane (hw x 16 bytes) is read ONCE into registers, mean and the
+// centred second moment are reduced over the workgroup (fp32, fixed shuffle tree + wave order: deterministic, and a
+// function of the image alone, so batch-independent), the affine is applied from the registers.  No records, no
+// second pass over memory, and in-place operation is safe (a workgroup reads all it will write before writing).
+// Round 3 measurement (profiles/r03_adain_ab.txt): folding the same AdaIN into the consumer conv (tile records from
+// the producer, merge + LDS patch rewrite in conv_fullkw_kernel) costs 6.5 us in the producer and 17 us in the
+// consumer, on 256 workgroups that own their CUs outright; this kernel is ~4 us of a quarter-occupied GPU.
+template <typename T, int PPT>
+__global__ void __launch_bounds__(256)
+instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x, int hw, int c,
+                      const float* __restrict__ style_gb, int ld_gb) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float s_red[2][4][VEC];
+    const int cvn = c / VEC;
+    const int img = blockIdx.x / cvn, cv = blockIdx.x - img * cvn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* xb = x + (int64_t)img * hw * ld_x + cv * VEC;
+    u128 raw[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int px = i * 256 + tid;
+        raw[i] = ld128(xb + (int64_t)(px < hw ? px : hw - 1) * ld_x);   // clamped: every load unconditional
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        float f[VEC];
+        unpack16<T>(raw[i], f);
+        const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += f[k] * live;
+    }
+    float mean[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) s_red[0][wave][k] = v;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)hw;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) mean[k] = (((s_red[0][0][k] + s_red[0][1][k]) + s_red[0][2][k]) + s_red[0][3][k]) * inv;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        float f[VEC];
+        unpack16<T>(raw[i], f);
+        const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float dv = (f[k] - mean[k]) * live;
+            acc[k] += dv * dv;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) s_red[1][wave][k] = v;
+    }
+    __syncthreads();
+    float sc[VEC], sh[VEC];
+    float gam[VEC], bet[VEC];
+    if (style_gb) {   // one wave-uniform branch, unconditional loads inside
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            gam[k] = style_gb[(int64_t)img * ld_gb + cv * VEC + k];
+            bet[k] = style_gb[(int64_t)img * ld_gb + c + cv * VEC + k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) gam[k] = 1.0f, bet[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float var = (((s_red[1][0][k] + s_red[1][1][k]) + s_red[1][2][k]) + s_red[1][3][k]) * inv;   // biased
+        const float rstd = 1.0f / sqrtf(var + IN_EPS);
+        sc[k] = gam[k] * rstd;
+        sh[k] = bet[k] - gam[k] * rstd * mean[k];
+    }
+    T* ob = out + (int64_t)img * hw * ld_out + cv * VEC;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int px = i * 256 + tid;
+        if (px >= hw) break;
+        float f[VEC];
+        unpack16<T>(raw[i], f);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) f[k] = fmaf(f[k], sc[k], sh[k]);
+        st128(ob + (int64_t)px * ld_out, pack16<T>(f));
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 affine_apply_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
@@ -711,6 +809,35 @@ extern "C" int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int
                   (const StatRec*)partials, hw, c, cpx, chunks, style_gb, ld_gb);
     }
     return vt_check_launch("vt_instnorm_apply_stats");
+}
+
+// AdaIN of a small plane in one launch (instnorm_plane_kernel); hw <= 4096, else VT_ERR_UNSUPPORTED.
+extern "C" int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
+                                 const float* style_gb, int ld_gb, int dtype, vt_stream stream) {
+    VT_REQUIRE(out && x, "vt_instnorm_plane: null tensor");
+    VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_instnorm_plane: c must be a positive multiple of 8");
+    VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_plane: dtype");
+    if (hw > 4096) {
+        vt_set_error("vt_instnorm_plane: plane too large for the register-resident form (hw <= 4096)");
+        return VT_ERR_UNSUPPORTED;
+    }
+    const unsigned nblk = (unsigned)(n * (c / (dtype == VT_F32 ? 4 : 8)));
+#define VT_PLANE(TT, P_)                                                                              \
+    {                                                                                                 \
+        auto k = instnorm_plane_kernel<TT, P_>;                                                       \
+        VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (TT*)out, ld_out, (const TT*)x, ld_x, hw, c,      \
+                  style_gb, ld_gb);                                                                   \
+    }
+    const int ppt = (hw + 255) / 256;
+    if (dtype == VT_F32) {
+        if (ppt <= 1) VT_PLANE(float, 1) else if (ppt <= 4) VT_PLANE(float, 4) else if (ppt <= 8) VT_PLANE(float, 8)
+        else VT_PLANE(float, 16)
+    } else {
+        if (ppt <= 1) VT_PLANE(bf16_t, 1) else if (ppt <= 4) VT_PLANE(bf16_t, 4) else if (ppt <= 8) VT_PLANE(bf16_t, 8)
+        else VT_PLANE(bf16_t, 16)
+    }
+#undef VT_PLANE
+    return vt_check_launch("vt_instnorm_plane");
 }
 
 // AdaIN in two launches (statistics + fused finalize/apply) when the tensor is small enough for

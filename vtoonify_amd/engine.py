@@ -500,7 +500,14 @@ class VToonifyEngine:
         # per-tile {mean, M2} records with its output, the consumer normalises its input patch in LDS -- no
         # statistics launch, no normalisation launch, no normalised copy of the tensor (12 AdaINs per frame)
         fuse_adain = False
-        if self.dual and has_res and os.environ.get("VT_FUSE_ADAIN", "1") != "0":
+        # VT_ADAIN: "plane" (default) = one vt_instnorm_plane launch per AdaIN (statistics + affine from registers, ~4 us on
+        # a quarter of the GPU) between plain convs; "fused" = round 2's tile records + in-LDS rewrite inside the whole-K convs
+        # (no extra launch, but +6.5 us in the producer and +17 us in the consumer of conv_fullkw_kernel, which owns every CU
+        # it runs on: profiles/r03_adain_ab.txt); anything else = the chunk-record path below.
+        adain_mode = os.environ.get("VT_ADAIN", "plane")
+        plane_adain = self.dual and has_res and adain_mode == "plane" and hw <= 4096
+        if self.dual and has_res and not plane_adain and adain_mode in ("plane", "fused") and \
+                os.environ.get("VT_FUSE_ADAIN", "1") != "0":
             kinds = [self._conv_kind(src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                                      weight=self.w[f"res.{r}.conv"], cout=cf, kh=3, kw=3, pad=_DIL[r], dil=_DIL[r],
                                      out=tmp, ld_out=cf) for r in range(1, 7)]
@@ -520,9 +527,34 @@ class VToonifyEngine:
                           bias=sd[f"{rk}.{ii}.conv2.bias"], act=ACT_LRELU, alpha=1 / SQRT2, beta=1 / SQRT2,
                           resid=feat, ld_res=cf, out=nxt, ld_out=cf,
                           tile_stats=ts[0] if fuse_adain else None,
-                          stats_part=ws if (self.dual and has_res and hw <= 16384 and fuse_stats and not fuse_adain) else None)
+                          stats_part=ws if (self.dual and has_res and hw <= 16384 and fuse_stats and not fuse_adain
+                                            and not plane_adain) else None)
             feat = nxt
-            if self.dual and has_res and fuse_adain:
+            if plane_adain:
+                r = ii + 1
+                dil = _DIL[r]
+                gb1, gb2 = plan.bufs[f"gb.res.{r}.norm"], plan.bufs[f"gb.res.{r}.norm2"]
+                ldg = 0 if ns == 1 else gb1.shape[1]
+
+                def _plane(dst, src, gb):
+                    ops.append((lib.vt_instnorm_plane,
+                                (C.c_void_p(dst.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
+                                 C.c_void_p(gb.data_ptr()), ldg, dt),
+                                {"name": "adain", "kernel": "instnorm_plane", "flops": 0,
+                                 "bytes": 2 * B * hw * cf * self.esz}))
+                # AdaResBlock (dualstylegan.py:38-45): conv(AdaIN(feat)) -> conv2(AdaIN(.)) * d_s + feat
+                _plane(nrm_res, feat, gb1)                      # `feat` itself is the residual below: not in place
+                self._op_conv(ops, plan, src0=nrm_res, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                              weight=self.w[f"res.{r}.conv"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
+                              bias=sd[f"res.{r}.conv.1.bias"], act=ACT_LRELU, gain=SQRT2, out=tmp, ld_out=cf)
+                _plane(tmp, tmp, gb2)                           # in place: nothing else reads the raw tensor
+                nxt = ping[pp]; pp ^= 1
+                self._op_conv(ops, plan, src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
+                              weight=self.w[f"res.{r}.conv2"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
+                              bias=sd[f"res.{r}.conv2.1.bias"], act=ACT_LRELU, gain=SQRT2, alpha_dev=ds, beta=1.0,
+                              resid=feat, ld_res=cf, out=nxt, ld_out=cf)
+                feat = nxt
+            elif self.dual and has_res and fuse_adain:
                 r = ii + 1
                 dil = _DIL[r]
                 gb1, gb2 = plan.bufs[f"gb.res.{r}.norm"], plan.bufs[f"gb.res.{r}.norm2"]
