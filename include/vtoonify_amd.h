@@ -310,9 +310,10 @@ int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int ld_x, int 
 /* AdaIN(x) of a small plane (hw <= 4096: the trunk of frames up to 512x512 inputs) in ONE launch, statistics
  * included: one workgroup per (image, 16-byte channel vector) holds its slice in registers.  nn.InstanceNorm2d
  * (biased variance, eps 1e-5) + the style affine (model/stylegan/dualstylegan.py:6-21).  `out` may alias `x`.
- * VT_ERR_UNSUPPORTED for larger planes. */
-int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
-                      const float* style_gb, int ld_gb, int dtype, vt_stream stream);
+ * absdiff_other != NULL: the AdaIN of cat[x, |x - other|] (Fusion.forward, model/vtoonify.py:125) into the 2c channels
+ * of `out` (style_gb = [gamma 2c | beta 2c]; not in place).  VT_ERR_UNSUPPORTED for larger planes. */
+int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, const void* absdiff_other, int ld_other,
+                      int n, int hw, int c, const float* style_gb, int ld_gb, int dtype, vt_stream stream);
 /* out[p][c] = x*scale+shift  (and the |x-other| half when absdiff_other != NULL). */
 int vt_affine_apply(void* out, int ld_out, const void* x, int ld_x,
                     const void* absdiff_other, int ld_other, const float* scale,

@@ -705,24 +705,39 @@ def test_instnorm_plane_one_launch(dev, dtype):
         xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
         gbt = T(gb, dev)
         out = torch.zeros_like(xt)
-        assert lib.vt_instnorm_plane(out.data_ptr(), Cc, xt.data_ptr(), Cc, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
+        assert lib.vt_instnorm_plane(out.data_ptr(), Cc, xt.data_ptr(), Cc, None, 0, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
                                      K._stream(xt)) == 0, lib.vt_last_error()
         ref = gb[:, :Cc].reshape(N, Cc, 1, 1) * O.instance_norm(xq) + gb[:, Cc:].reshape(N, Cc, 1, 1)
         assert rel_err(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
         inpl = xt.clone()                                       # out aliases x
-        assert lib.vt_instnorm_plane(inpl.data_ptr(), Cc, inpl.data_ptr(), Cc, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
+        assert lib.vt_instnorm_plane(inpl.data_ptr(), Cc, inpl.data_ptr(), Cc, None, 0, N, hw, Cc, gbt.data_ptr(), 2 * Cc, code,
                                      K._stream(xt)) == 0
         assert torch.equal(inpl, out)
         one = torch.zeros_like(xt[-1:])                         # the last image alone
-        assert lib.vt_instnorm_plane(one.data_ptr(), Cc, xt[-1:].contiguous().data_ptr(), Cc, 1, hw, Cc,
+        assert lib.vt_instnorm_plane(one.data_ptr(), Cc, xt[-1:].contiguous().data_ptr(), Cc, None, 0, 1, hw, Cc,
                                      gbt[-1:].contiguous().data_ptr(), 2 * Cc, code, K._stream(xt)) == 0
         assert torch.equal(one[0], out[-1])
         plain = torch.zeros_like(xt)                            # no style: InstanceNorm2d alone
-        assert lib.vt_instnorm_plane(plain.data_ptr(), Cc, xt.data_ptr(), Cc, N, hw, Cc, None, 0, code, K._stream(xt)) == 0
+        assert lib.vt_instnorm_plane(plain.data_ptr(), Cc, xt.data_ptr(), Cc, None, 0, N, hw, Cc, None, 0, code,
+                                     K._stream(xt)) == 0
         assert rel_err(plain.float().cpu().permute(0, 3, 1, 2).numpy(), O.instance_norm(xq)) < \
             (F32_TOL if dtype == torch.float32 else 8e-3)
+        # Fusion.forward's norm (vtoonify.py:125): AdaIN of cat[x, |x - other|] into 2C channels, against the oracle and,
+        # bit for bit up to the statistics' rounding, against the two-launch path (vt_instnorm_stats + vt_affine_apply)
+        o = g.standard_normal((N, Cc, H, W)).astype(np.float32)
+        ot = K.nchw_to_nhwc(T(o, dev), dtype)
+        oq = ot.float().cpu().permute(0, 3, 1, 2).numpy()
+        gb2 = g.standard_normal((N, 4 * Cc)).astype(np.float32)
+        cat = torch.zeros((N, H, W, 2 * Cc), dtype=dtype, device=dev)
+        assert lib.vt_instnorm_plane(cat.data_ptr(), 2 * Cc, xt.data_ptr(), Cc, ot.data_ptr(), Cc, N, hw, Cc,
+                                     T(gb2, dev).data_ptr(), 4 * Cc, code, K._stream(xt)) == 0, lib.vt_last_error()
+        full = np.concatenate([xq, np.abs(xq - oq)], 1)
+        ref = gb2[:, :2 * Cc].reshape(N, 2 * Cc, 1, 1) * O.instance_norm(full) + gb2[:, 2 * Cc:].reshape(N, 2 * Cc, 1, 1)
+        assert rel_err(cat.float().cpu().permute(0, 3, 1, 2).numpy(), ref) < (F32_TOL if dtype == torch.float32 else 8e-3)
+        assert lib.vt_instnorm_plane(xt.data_ptr(), 2 * Cc, xt.data_ptr(), Cc, ot.data_ptr(), Cc, N, hw, Cc, None, 0, code,
+                                     K._stream(xt)) == 1   # VT_ERR_ARG: the cat form cannot run in place
     big = torch.zeros((1, 65, 64, 8), dtype=dtype, device=dev)
-    assert lib.vt_instnorm_plane(big.data_ptr(), 8, big.data_ptr(), 8, 1, 65 * 64, 8, None, 0, code, K._stream(big)) == 2   # VT_ERR_UNSUPPORTED
+    assert lib.vt_instnorm_plane(big.data_ptr(), 8, big.data_ptr(), 8, None, 0, 1, 65 * 64, 8, None, 0, code, K._stream(big)) == 2   # VT_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1035,6 +1050,11 @@ def test_conv_transpose_blur_kernel(dev, dtype):
         y = out.float().cpu().permute(0, 3, 1, 2).numpy()
         assert tuple(y.shape) == ref.shape
         assert rel_err(y, ref) < t, (N, cin, H, W, cout, hint)
+        # the other tile width gives the same bits (the width is chosen from the batch size: a frame inside a batch must
+        # equal the frame alone)
+        out_w = torch.zeros_like(out)
+        K.conv2d(**{**kw, "out": out_w, "tile_hint": 32 if (hint or 16) == 16 else 16})
+        assert torch.equal(out_w, out), (N, cin, H, W, cout, hint)
         # the polyphase form of the same layer (blur folded into four 3x3 filters)
         wpp = K.modulate_weight(T(w, dev), torch.ones(cin, device=dev), 1.0, False, fir=T(fir, dev), out_dtype=dtype)
         out2 = torch.zeros_like(out)

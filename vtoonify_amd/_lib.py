@@ -110,8 +110,8 @@ _SIGS = {
     "vt_frame_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p]),
     "vt_frame_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "vt_instnorm_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                   C.c_int, C.c_int, C.c_void_p]),
+    "vt_instnorm_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vt_instnorm_apply_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vt_affine_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

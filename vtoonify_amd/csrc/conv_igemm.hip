@@ -1763,7 +1763,10 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         t.kind = 5;
         t.bm = 20 * 28;
         const int64_t tiles = (int64_t)vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28);
-        t.bn = (hint % 1000 == 16 || (hint % 1000 != 32 && tiles * vt_cdiv(a.coutT, 32) < 256 && a.coutT >= 32)) ? 16 : 32;
+        // (the batch counts: tile width changes which workgroup computes a channel, not the order of its sum -- results are
+        // bit-identical, tests/test_ops.py -- and at 4 frames the deepest level fills the GPU with 32-channel tiles, which
+        // read every patch half as often: 99 -> 81 us)
+        t.bn = (hint % 1000 == 16 || (hint % 1000 != 32 && a.N * tiles * vt_cdiv(a.coutT, 32) < 256 && a.coutT >= 32)) ? 16 : 32;
         t.splitk = 1;
         return t;
     }
@@ -2016,7 +2019,9 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         // double-buffered chunks (one workgroup per CU) only pay on the 16-channel tiles of the deepest layer
         // (33 vs 37 us); the 32-channel tiles run single-stage with two workgroups per CU (44 vs 51 us at 512->256)
         const char* de = getenv("VT_UPBLUR_DB");    // A/B: minimum chunk count of the double-buffered form
-        const bool db = de ? chunks >= atoi(de) : (t.bn == 16 && chunks >= 4);
+        // ... and on 32-channel tiles when all workgroups are resident at once anyway (<= 512: 81 vs 86 us at 4 frames)
+        const int64_t wgs_all = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28) * vt_cdiv(a.coutT, t.bn);
+        const bool db = de ? chunks >= atoi(de) : (chunks >= 4 && (t.bn == 16 || wgs_all <= 512));
         // single-chunk layers with many tiles per CU (the 1024^2 level): persistent workgroups, resident weights.
         // VT_UPBLUR_PERSIST = minimum number of workgroups for the persistent form (0 = never; tests use 1)
         const char* pe = getenv("VT_UPBLUR_PERSIST");

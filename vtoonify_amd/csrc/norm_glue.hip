@@ -260,93 +260,131 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
 // Round 3 measurement (profiles/r03_adain_ab.txt): folding the same AdaIN into the consumer conv (tile records from
 // the producer, merge + LDS patch rewrite in conv_fullkw_kernel) costs 6.5 us in the producer and 17 us in the
 // consumer, on 256 workgroups that own their CUs outright; this kernel is ~4 us of a quarter-occupied GPU.
-template <typename T, int PPT>
+template <typename T, int PPT, bool HAS_OTHER>
 __global__ void __launch_bounds__(256)
-instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x, int hw, int c,
+instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
+                      const T* __restrict__ other, int ld_o, int hw, int c,
                       const float* __restrict__ style_gb, int ld_gb) {
     constexpr int VEC = 16 / sizeof(T);
-    __shared__ float s_red[2][4][VEC];
+    constexpr int HALVES = HAS_OTHER ? 2 : 1;   // second half: |x - other| (Fusion.forward, vtoonify.py:125) -> out[.., c + ch]
+    __shared__ float s_red[2][HALVES][4][VEC];
     const int cvn = c / VEC;
     const int img = blockIdx.x / cvn, cv = blockIdx.x - img * cvn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* xb = x + (int64_t)img * hw * ld_x + cv * VEC;
-    u128 raw[PPT];
+    const T* ob = HAS_OTHER ? other + (int64_t)img * hw * ld_o + cv * VEC : nullptr;
+    u128 raw[HALVES][PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int px = i * 256 + tid;
-        raw[i] = ld128(xb + (int64_t)(px < hw ? px : hw - 1) * ld_x);   // clamped: every load unconditional
+        const int pc = px < hw ? px : hw - 1;   // clamped: every load unconditional
+        raw[0][i] = ld128(xb + (int64_t)pc * ld_x);
+        if (HAS_OTHER) raw[HALVES - 1][i] = ld128(ob + (int64_t)pc * ld_o);
     }
-    float acc[VEC];
+    // value k of pixel i in half h, from the registers
+    auto values = [&](int i, float (&f)[HALVES][VEC]) {
+        unpack16<T>(raw[0][i], f[0]);
+        if (HAS_OTHER) {
+            float g[VEC];
+            unpack16<T>(raw[HALVES - 1][i], g);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+            for (int k = 0; k < VEC; ++k) f[HALVES - 1][k] = fabsf(f[0][k] - g[k]);
+        }
+    };
+    float acc[HALVES][VEC], mean[HALVES][VEC];
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[h][k] = 0.0f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        float f[VEC];
-        unpack16<T>(raw[i], f);
+        float f[HALVES][VEC];
+        values(i, f);
         const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += f[k] * live;
-    }
-    float mean[VEC];
+        for (int h = 0; h < HALVES; ++h)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) s_red[0][wave][k] = v;
+            for (int k = 0; k < VEC; ++k) acc[h][k] += f[h][k] * live;
     }
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float v = acc[h][k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) s_red[0][h][wave][k] = v;
+        }
     __syncthreads();
     const float inv = 1.0f / (float)hw;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) mean[k] = (((s_red[0][0][k] + s_red[0][1][k]) + s_red[0][2][k]) + s_red[0][3][k]) * inv;
+    for (int h = 0; h < HALVES; ++h)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        for (int k = 0; k < VEC; ++k) {
+            mean[h][k] = (((s_red[0][h][0][k] + s_red[0][h][1][k]) + s_red[0][h][2][k]) + s_red[0][h][3][k]) * inv;
+            acc[h][k] = 0.0f;
+        }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        float f[VEC];
-        unpack16<T>(raw[i], f);
+        float f[HALVES][VEC];
+        values(i, f);
         const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const float dv = (f[k] - mean[k]) * live;
-            acc[k] += dv * dv;
-        }
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float dv = (f[h][k] - mean[h][k]) * live;
+                acc[h][k] += dv * dv;
+            }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) s_red[1][wave][k] = v;
-    }
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float v = acc[h][k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) s_red[1][h][wave][k] = v;
+        }
     __syncthreads();
-    float sc[VEC], sh[VEC];
-    float gam[VEC], bet[VEC];
+    const int ctot = c * HALVES;
+    float sc[HALVES][VEC], sh[HALVES][VEC];
     if (style_gb) {   // one wave-uniform branch, unconditional loads inside
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            gam[k] = style_gb[(int64_t)img * ld_gb + cv * VEC + k];
-            bet[k] = style_gb[(int64_t)img * ld_gb + c + cv * VEC + k];
-        }
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                sc[h][k] = style_gb[(int64_t)img * ld_gb + h * c + cv * VEC + k];            // gamma
+                sh[h][k] = style_gb[(int64_t)img * ld_gb + ctot + h * c + cv * VEC + k];     // beta
+            }
     } else {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) gam[k] = 1.0f, bet[k] = 0.0f;
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) sc[h][k] = 1.0f, sh[h][k] = 0.0f;
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const float var = (((s_red[1][0][k] + s_red[1][1][k]) + s_red[1][2][k]) + s_red[1][3][k]) * inv;   // biased
-        const float rstd = 1.0f / sqrtf(var + IN_EPS);
-        sc[k] = gam[k] * rstd;
-        sh[k] = bet[k] - gam[k] * rstd * mean[k];
-    }
-    T* ob = out + (int64_t)img * hw * ld_out + cv * VEC;
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float var =
+                (((s_red[1][h][0][k] + s_red[1][h][1][k]) + s_red[1][h][2][k]) + s_red[1][h][3][k]) * inv;   // biased
+            const float rstd = 1.0f / sqrtf(var + IN_EPS);
+            const float gamma = sc[h][k];
+            sc[h][k] = gamma * rstd;
+            sh[h][k] = sh[h][k] - gamma * rstd * mean[h][k];
+        }
+    T* outb = out + (int64_t)img * hw * ld_out + cv * VEC;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int px = i * 256 + tid;
         if (px >= hw) break;
-        float f[VEC];
-        unpack16<T>(raw[i], f);
+        float f[HALVES][VEC];
+        values(i, f);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) f[k] = fmaf(f[k], sc[k], sh[k]);
-        st128(ob + (int64_t)px * ld_out, pack16<T>(f));
+        for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) f[h][k] = fmaf(f[h][k], sc[h][k], sh[h][k]);
+            st128(outb + (int64_t)px * ld_out + h * c, pack16<T>(f[h]));
+        }
     }
 }
 
@@ -812,30 +850,33 @@ extern "C" int vt_instnorm_apply_stats(void* out, int ld_out, const void* x, int
 }
 
 // AdaIN of a small plane in one launch (instnorm_plane_kernel); hw <= 4096, else VT_ERR_UNSUPPORTED.
-extern "C" int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, int n, int hw, int c,
-                                 const float* style_gb, int ld_gb, int dtype, vt_stream stream) {
+extern "C" int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x, const void* absdiff_other, int ld_other,
+                                 int n, int hw, int c, const float* style_gb, int ld_gb, int dtype, vt_stream stream) {
     VT_REQUIRE(out && x, "vt_instnorm_plane: null tensor");
     VT_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 8 == 0, "vt_instnorm_plane: c must be a positive multiple of 8");
     VT_REQUIRE(dtype == VT_F32 || dtype == VT_BF16, "vt_instnorm_plane: dtype");
+    VT_REQUIRE(!absdiff_other || out != x, "vt_instnorm_plane: the cat[x, |x - other|] form cannot run in place");
     if (hw > 4096) {
         vt_set_error("vt_instnorm_plane: plane too large for the register-resident form (hw <= 4096)");
         return VT_ERR_UNSUPPORTED;
     }
     const unsigned nblk = (unsigned)(n * (c / (dtype == VT_F32 ? 4 : 8)));
-#define VT_PLANE(TT, P_)                                                                              \
+#define VT_PLANE(TT, P_, HO_)                                                                         \
     {                                                                                                 \
-        auto k = instnorm_plane_kernel<TT, P_>;                                                       \
-        VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (TT*)out, ld_out, (const TT*)x, ld_x, hw, c,      \
-                  style_gb, ld_gb);                                                                   \
+        auto k = instnorm_plane_kernel<TT, P_, HO_>;                                                  \
+        VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (TT*)out, ld_out, (const TT*)x, ld_x,             \
+                  (const TT*)absdiff_other, ld_other, hw, c, style_gb, ld_gb);                        \
     }
+#define VT_PLANE_P(TT, HO_)                                                                           \
+    if (ppt <= 1) VT_PLANE(TT, 1, HO_) else if (ppt <= 4) VT_PLANE(TT, 4, HO_)                        \
+    else if (ppt <= 8) VT_PLANE(TT, 8, HO_) else VT_PLANE(TT, 16, HO_)
     const int ppt = (hw + 255) / 256;
     if (dtype == VT_F32) {
-        if (ppt <= 1) VT_PLANE(float, 1) else if (ppt <= 4) VT_PLANE(float, 4) else if (ppt <= 8) VT_PLANE(float, 8)
-        else VT_PLANE(float, 16)
+        if (absdiff_other) { VT_PLANE_P(float, true) } else { VT_PLANE_P(float, false) }
     } else {
-        if (ppt <= 1) VT_PLANE(bf16_t, 1) else if (ppt <= 4) VT_PLANE(bf16_t, 4) else if (ppt <= 8) VT_PLANE(bf16_t, 8)
-        else VT_PLANE(bf16_t, 16)
+        if (absdiff_other) { VT_PLANE_P(bf16_t, true) } else { VT_PLANE_P(bf16_t, false) }
     }
+#undef VT_PLANE_P
 #undef VT_PLANE
     return vt_check_launch("vt_instnorm_plane");
 }

@@ -538,7 +538,7 @@ class VToonifyEngine:
 
                 def _plane(dst, src, gb):
                     ops.append((lib.vt_instnorm_plane,
-                                (C.c_void_p(dst.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
+                                (C.c_void_p(dst.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, C.c_void_p(0), 0, B, hw, cf,
                                  C.c_void_p(gb.data_ptr()), ldg, dt),
                                 {"name": "adain", "kernel": "instnorm_plane", "flops": 0,
                                  "bytes": 2 * B * hw * cf * self.esz}))
@@ -640,12 +640,26 @@ class VToonifyEngine:
                     sh = self._buf(plan, f"fsh{lvl}", (B, 2 * co), f32)
                     ws = self._buf(plan, f"fws{lvl}", (max(K.instnorm_ws_bytes(B, hw, 2 * co), 16),), torch.uint8)
                     gb = plan.bufs[f"gb.fus.{lvl}"]
-                    ops.append((lib.vt_instnorm_stats,
-                                (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
-                                 C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
-                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
-                                {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
-                                 "bytes": 2 * B * hw * co * self.esz}))
+                    # VT_FUSION_PLANE=1: statistics + affine of cat[f_G, |f_G - f_E|] of the small planes in ONE register-resident
+                    # launch (vt_instnorm_plane) instead of partial + finalize + apply -- 4 launches fewer per frame, measured
+                    # 0.6 % SLOWER at 4 frames (1110 vs 1117 frames/s same box, profiles/r03_adain_ab.txt: unlike the trunk's
+                    # AdaIN it replaces streaming kernels, not work inside a CU-owning conv), so it stays opt-in
+                    fus_plane = (not self.fuse_gate and hw <= 4096 and os.environ.get("VT_FUSION_PLANE", "0") == "1")
+                    if fus_plane:
+                        nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                        ops.append((lib.vt_instnorm_plane,
+                                    (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                     C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
+                                     0 if ns == 1 else gb.shape[1], dt),
+                                    {"name": "adain_cat", "kernel": "instnorm_plane", "flops": 0,
+                                     "bytes": 4 * B * hw * co * self.esz}))
+                    else:
+                        ops.append((lib.vt_instnorm_stats,
+                                    (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
+                                     C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
+                                     0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
+                                    {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
+                                     "bytes": 2 * B * hw * co * self.esz}))
                     mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
                     if self.fuse_gate:
                         # AdaIN affine + |f_G - f_E| + mask conv + [skip | f_E * m] pack in ONE launch (vt_fusion_gate)
@@ -659,13 +673,14 @@ class VToonifyEngine:
                                     {"name": "fusion_gate", "kernel": "fusion_gate", "flops": 2 * B * hw * 2 * co * 9,
                                      "join": True, "bytes": B * hw * (2 * co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                     else:
-                        nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                        ops.append((lib.vt_affine_apply,
-                                    (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
-                                     C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
-                                     B, hw, co, dt),
-                                    {"name": "affine", "kernel": "affine_apply", "flops": 0,
-                                     "bytes": 4 * B * hw * co * self.esz}))
+                        if not fus_plane:
+                            nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                            ops.append((lib.vt_affine_apply,
+                                        (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                         C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
+                                         B, hw, co, dt),
+                                        {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                         "bytes": 4 * B * hw * co * self.esz}))
                         self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
                                       weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
                                       bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
