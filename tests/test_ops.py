@@ -697,7 +697,8 @@ def test_instnorm_plane_one_launch(dev, dtype):
     lib = _lib.lib()
     g = np.random.default_rng(31)
     code = K.dt_code(dtype)
-    for N, Cc, H, W in ((2, 16, 16, 16), (2, 24, 32, 32), (3, 16, 37, 29), (1, 8, 45, 50), (1, 16, 64, 64)):
+    for N, Cc, H, W in ((2, 16, 16, 16), (2, 24, 32, 32), (3, 16, 37, 29), (1, 8, 45, 50), (1, 16, 64, 64),
+                        (2, 64, 32, 32), (1, 32, 16, 15), (2, 32, 40, 33)):   # 64-byte rows per workgroup (VPW 4, 2)
         hw = H * W
         x = (g.standard_normal((N, Cc, H, W)) * 2 + 1).astype(np.float32)
         gb = g.standard_normal((N, 2 * Cc)).astype(np.float32)

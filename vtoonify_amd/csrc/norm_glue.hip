@@ -253,35 +253,59 @@ instnorm_apply_small_kernel(T* __restrict__ out, int ld_out, const T* __restrict
 }
 
 // AdaIN of a SMALL plane in ONE launch, statistics included (the 32x32-pixel trunk, 12 per frame).  One workgroup per
-// (image, 16-byte channel vector): its slice of the plane (hw x 16 bytes) is read ONCE into registers, mean and the
-// centred second moment are reduced over the workgroup (fp32, fixed shuffle tree + wave order: deterministic, and a
-// function of the image alone, so batch-independent), the affine is applied from the registers.  No records, no
-// second pass over memory, and in-place operation is safe (a workgroup reads all it will write before writing).
+// (image, VPW 16-byte channel vectors): its slice of the plane is read ONCE into registers, mean and the centred second
+// moment are reduced over the workgroup (fp32, fixed shuffle tree + wave order: deterministic, and a function of the image
+// alone, so batch-independent), the affine is applied from the registers.  No records, no second pass over memory, and
+// in-place operation is safe (a workgroup reads all it will write before writing).  VPW adjacent lanes hold adjacent
+// vectors of one pixel: with VPW = 4 a workgroup reads and writes 64 contiguous bytes per pixel (VPW = 1, 16 bytes per
+// pixel at a 1 KB stride, made every 128-byte line of the output the target of 8 partial writes from 8 workgroups:
+// 16.7 us per launch for 8 MB of traffic).
 // Round 3 measurement (profiles/r03_adain_ab.txt): folding the same AdaIN into the consumer conv (tile records from
 // the producer, merge + LDS patch rewrite in conv_fullkw_kernel) costs 6.5 us in the producer and 17 us in the
-// consumer, on 256 workgroups that own their CUs outright; this kernel is ~4 us of a quarter-occupied GPU.
-template <typename T, int PPT, bool HAS_OTHER>
+// consumer, on 256 workgroups that own their CUs outright.
+template <typename T, int PPT, int VPW, bool HAS_OTHER>
 __global__ void __launch_bounds__(256)
 instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, int ld_x,
                       const T* __restrict__ other, int ld_o, int hw, int c,
                       const float* __restrict__ style_gb, int ld_gb) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int HALVES = HAS_OTHER ? 2 : 1;   // second half: |x - other| (Fusion.forward, vtoonify.py:125) -> out[.., c + ch]
-    __shared__ float s_red[2][HALVES][4][VEC];
-    const int cvn = c / VEC;
-    const int img = blockIdx.x / cvn, cv = blockIdx.x - img * cvn;
+    constexpr int PPP = 256 / VPW;              // pixels per pass of the workgroup
+    __shared__ float s_red[2][HALVES][4][VPW][VEC];
+    const int cgn = c / (VEC * VPW);
+    const int img = blockIdx.x / cgn, cg = blockIdx.x - img * cgn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const T* xb = x + (int64_t)img * hw * ld_x + cv * VEC;
-    const T* ob = HAS_OTHER ? other + (int64_t)img * hw * ld_o + cv * VEC : nullptr;
+    const int vl = tid % VPW, pl = tid / VPW;   // vector of the group, pixel of the pass
+    const int ch0 = (cg * VPW + vl) * VEC;      // first channel of this thread
+    const T* xb = x + (int64_t)img * hw * ld_x + ch0;
+    const T* ob = HAS_OTHER ? other + (int64_t)img * hw * ld_o + ch0 : nullptr;
+    // the style affine first: its loads fly with the plane's (issued after the statistics they were a third dependent
+    // memory round trip of a kernel that is nothing but a latency chain)
+    const int ctot = c * HALVES;
+    float sc[HALVES][VEC], sh[HALVES][VEC];
+    if (style_gb) {   // one wave-uniform branch, unconditional loads inside
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                sc[h][k] = style_gb[(int64_t)img * ld_gb + h * c + ch0 + k];            // gamma
+                sh[h][k] = style_gb[(int64_t)img * ld_gb + ctot + h * c + ch0 + k];     // beta
+            }
+    } else {
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) sc[h][k] = 1.0f, sh[h][k] = 0.0f;
+    }
     u128 raw[HALVES][PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int px = i * 256 + tid;
+        const int px = i * PPP + pl;
         const int pc = px < hw ? px : hw - 1;   // clamped: every load unconditional
         raw[0][i] = ld128(xb + (int64_t)pc * ld_x);
         if (HAS_OTHER) raw[HALVES - 1][i] = ld128(ob + (int64_t)pc * ld_o);
     }
-    // value k of pixel i in half h, from the registers
+    // the VEC values of pixel i in each half, from the registers
     auto values = [&](int i, float (&f)[HALVES][VEC]) {
         unpack16<T>(raw[0][i], f[0]);
         if (HAS_OTHER) {
@@ -290,6 +314,25 @@ instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, 
 #pragma unroll
             for (int k = 0; k < VEC; ++k) f[HALVES - 1][k] = fabsf(f[0][k] - g[k]);
         }
+    };
+    // sum over the workgroup's pixels: lanes VPW apart hold the same channels
+    auto reduce = [&](float (&acc)[HALVES][VEC], int slot) {
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float v = acc[h][k];
+#pragma unroll
+                for (int off = 32; off >= VPW; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane < VPW) s_red[slot][h][wave][vl][k] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                acc[h][k] = ((s_red[slot][h][0][vl][k] + s_red[slot][h][1][vl][k]) + s_red[slot][h][2][vl][k]) +
+                            s_red[slot][h][3][vl][k];
     };
     float acc[HALVES][VEC], mean[HALVES][VEC];
 #pragma unroll
@@ -300,34 +343,26 @@ instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, 
     for (int i = 0; i < PPT; ++i) {
         float f[HALVES][VEC];
         values(i, f);
-        const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
+        const float live = (i * PPP + pl < hw) ? 1.0f : 0.0f;
 #pragma unroll
         for (int h = 0; h < HALVES; ++h)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[h][k] += f[h][k] * live;
     }
-#pragma unroll
-    for (int h = 0; h < HALVES; ++h)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            float v = acc[h][k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) s_red[0][h][wave][k] = v;
-        }
-    __syncthreads();
+    reduce(acc, 0);
     const float inv = 1.0f / (float)hw;
 #pragma unroll
     for (int h = 0; h < HALVES; ++h)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            mean[h][k] = (((s_red[0][h][0][k] + s_red[0][h][1][k]) + s_red[0][h][2][k]) + s_red[0][h][3][k]) * inv;
+            mean[h][k] = acc[h][k] * inv;
             acc[h][k] = 0.0f;
         }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         float f[HALVES][VEC];
         values(i, f);
-        const float live = (i * 256 + tid < hw) ? 1.0f : 0.0f;
+        const float live = (i * PPP + pl < hw) ? 1.0f : 0.0f;
 #pragma unroll
         for (int h = 0; h < HALVES; ++h)
 #pragma unroll
@@ -336,46 +371,21 @@ instnorm_plane_kernel(T* __restrict__ out, int ld_out, const T* __restrict__ x, 
                 acc[h][k] += dv * dv;
             }
     }
+    reduce(acc, 1);
 #pragma unroll
     for (int h = 0; h < HALVES; ++h)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            float v = acc[h][k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) s_red[1][h][wave][k] = v;
-        }
-    __syncthreads();
-    const int ctot = c * HALVES;
-    float sc[HALVES][VEC], sh[HALVES][VEC];
-    if (style_gb) {   // one wave-uniform branch, unconditional loads inside
-#pragma unroll
-        for (int h = 0; h < HALVES; ++h)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                sc[h][k] = style_gb[(int64_t)img * ld_gb + h * c + cv * VEC + k];            // gamma
-                sh[h][k] = style_gb[(int64_t)img * ld_gb + ctot + h * c + cv * VEC + k];     // beta
-            }
-    } else {
-#pragma unroll
-        for (int h = 0; h < HALVES; ++h)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) sc[h][k] = 1.0f, sh[h][k] = 0.0f;
-    }
-#pragma unroll
-    for (int h = 0; h < HALVES; ++h)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const float var =
-                (((s_red[1][h][0][k] + s_red[1][h][1][k]) + s_red[1][h][2][k]) + s_red[1][h][3][k]) * inv;   // biased
+            const float var = acc[h][k] * inv;   // biased, as F.instance_norm
             const float rstd = 1.0f / sqrtf(var + IN_EPS);
             const float gamma = sc[h][k];
             sc[h][k] = gamma * rstd;
             sh[h][k] = sh[h][k] - gamma * rstd * mean[h][k];
         }
-    T* outb = out + (int64_t)img * hw * ld_out + cv * VEC;
+    T* outb = out + (int64_t)img * hw * ld_out + ch0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int px = i * 256 + tid;
+        const int px = i * PPP + pl;
         if (px >= hw) break;
         float f[HALVES][VEC];
         values(i, f);
@@ -860,17 +870,23 @@ extern "C" int vt_instnorm_plane(void* out, int ld_out, const void* x, int ld_x,
         vt_set_error("vt_instnorm_plane: plane too large for the register-resident form (hw <= 4096)");
         return VT_ERR_UNSUPPORTED;
     }
-    const unsigned nblk = (unsigned)(n * (c / (dtype == VT_F32 ? 4 : 8)));
-#define VT_PLANE(TT, P_, HO_)                                                                         \
+    // vectors per workgroup x pixels per thread: the widest rows (64 contiguous bytes per pixel) the plane's size and the
+    // channel count allow -- (4 x 4) 256 pixels, (4 x 16) 1024, (2 x 16) 2048, (1 x 16) 4096
+    const int vec = dtype == VT_F32 ? 4 : 8;
+    int vpw = hw <= 1024 ? 4 : hw <= 2048 ? 2 : 1;
+    while (vpw > 1 && c % (vec * vpw) != 0) vpw >>= 1;
+    const int ppt = (hw + 256 / vpw - 1) / (256 / vpw);
+    if (ppt > 16) vpw = 1;   // (a channel count that forced narrower rows than the plane's size wanted)
+    const unsigned nblk = (unsigned)(n * (c / (vec * vpw)));
+#define VT_PLANE(TT, P_, V_, HO_)                                                                     \
     {                                                                                                 \
-        auto k = instnorm_plane_kernel<TT, P_, HO_>;                                                  \
+        auto k = instnorm_plane_kernel<TT, P_, V_, HO_>;                                              \
         VT_LAUNCH(k, dim3(nblk), dim3(256), stream, (TT*)out, ld_out, (const TT*)x, ld_x,             \
                   (const TT*)absdiff_other, ld_other, hw, c, style_gb, ld_gb);                        \
     }
 #define VT_PLANE_P(TT, HO_)                                                                           \
-    if (ppt <= 1) VT_PLANE(TT, 1, HO_) else if (ppt <= 4) VT_PLANE(TT, 4, HO_)                        \
-    else if (ppt <= 8) VT_PLANE(TT, 8, HO_) else VT_PLANE(TT, 16, HO_)
-    const int ppt = (hw + 255) / 256;
+    if (vpw == 4 && hw <= 256) VT_PLANE(TT, 4, 4, HO_) else if (vpw == 4) VT_PLANE(TT, 16, 4, HO_)    \
+    else if (vpw == 2) VT_PLANE(TT, 16, 2, HO_) else VT_PLANE(TT, 16, 1, HO_)
     if (dtype == VT_F32) {
         if (absdiff_other) { VT_PLANE_P(float, true) } else { VT_PLANE_P(float, false) }
     } else {
