@@ -96,6 +96,8 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
             const int ks = k0 + u * TH_NW;
             const bool live = ks < nk;
             const int kb = (live ? ks : k0) * KSTEP;
+            // (predicated loads are right HERE: hipcc batches them -- all NF * UNR are issued before the first wait -- and dead
+            // lanes fetch nothing; the unconditional-at-a-clamped-offset form measured 124 -> 145 us over the 7 launches)
 #pragma unroll
             for (int f = 0; f < NF; ++f) fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
 #pragma unroll
