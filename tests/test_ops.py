@@ -405,6 +405,11 @@ def test_conv_c32_persistent_kernel(dev, monkeypatch):
     d = K.make_conv_desc(src0=x, c0=32, ld0=32, n=1, h=16, w=16, out_h=16, out_w=16, weight=x, cout=32, kh=3, kw=3,
                          pad=1, out=x, ld_out=32, dtype=K.VT_BF16)
     assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == 3
+    # cout = 32k (the encoder's 32 -> 128 conv): one group of 32 output channels per blockIdx.y, same kernel
+    for cout in (64, 128):
+        monkeypatch.setenv("VT_C32_BLOCKS", "2")
+        assert _conv_case(dev, torch.bfloat16, 2, 32, 21, 34, cout, 3, 1, 1, 1, act=K.ACT_LRELU, expect_kind=3) < t
+        monkeypatch.delenv("VT_C32_BLOCKS")
     # fp32 (parity mode) and dilated / strided 32->32 convs stay on the generic kernels
     assert _conv_case(dev, torch.float32, 1, 32, 19, 21, 32, 3, 1, 1, 1, act=K.ACT_LRELU) < F32_TOL
     assert _conv_case(dev, torch.bfloat16, 1, 32, 19, 21, 32, 3, 2, 1, 1) < t

@@ -213,7 +213,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
                         if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
                         f[4 * b + i] = v * ga;
                     }
-                    if (rgbf) {
+                    if (rgbf && p.dbg != 35) {   // (35: ablation, no dot products)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             r0 += f[4 * b + i] * rwt[0][b][i];
@@ -241,7 +241,7 @@ conv3x3_c64_kernel(const ConvArgs p, const GldsArgs g) {
                     rgbx[wm][a][l15][2] = r[a][2];
                 }
             }
-            vt_lds_barrier();
+            if (p.dbg != 34) vt_lds_barrier();   // (34: ablation, no exchange barrier)
             if (wn == 0 && q == 0) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {

@@ -1186,6 +1186,10 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     auto swz = [](int pr) -> int { return ((pr >> 2) & 1) << 1; };
 
     // ---- weights -> registers: fragment (tap, b): row n = b*16 + l15, k = q*8 .. q*8+7 ----------
+    // cout > 32 (the encoder's 32 -> 128 conv): blockIdx.y = the group of 32 output channels this workgroup owns -- its
+    // own 18 KB of weights in registers, the same patches (L2 / MALL hits after the first group), a 64-byte slice of
+    // every output pixel
+    const int cg = (int)blockIdx.y * 32;
     u128 wreg[9][TN];
     {
         const T* wg = (const T*)p.wgt;
@@ -1193,7 +1197,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int b = 0; b < TN; ++b)   // fragment order: (b, lane group q) <-> channels 8q + 4b .. +3
-                wreg[t][b] = ld128(wg + (int64_t)tile_row_channel<true>(b * 16 + l15) * p.K + t * 32 + q * 8);
+                wreg[t][b] = ld128(wg + (int64_t)(cg + tile_row_channel<true>(b * 16 + l15)) * p.K + t * 32 + q * 8);
     }
     const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
@@ -1238,7 +1242,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias[frag_channel<true>(b, q) + i];
+            for (int i = 0; i < 4; ++i) bvr[b][i] = p.bias[cg + frag_channel<true>(b, q) + i];
     }
     float rb0 = 0.0f, rb1 = 0.0f, rb2 = 0.0f;
     if (rgbf && p.rgb_bias) rb0 = p.rgb_bias[0], rb1 = p.rgb_bias[1], rb2 = p.rgb_bias[2];
@@ -1326,7 +1330,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                     }
                 }
                 // one 16-byte store per lane: the four lane groups write the pixel's 64 bytes
-                if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + q * 8, pack16<bf16_t>(f));
+                if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + cg + q * 8, pack16<bf16_t>(f));
                 if (rgbf) {
                     if (p.dbg != 3) {
                     r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
@@ -1728,7 +1732,8 @@ template <typename T>
 static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
     if (sizeof(T) != 2 || a.force_generic || a.transposed || a.in_scale) return false;
     if (a.taps != 9 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return false;
-    if (a.c0 != 32 || a.c1 != 0 || a.cout != 32 || a.phases != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.c0 != 32 || a.c1 != 0 || a.cout % 32 != 0 || a.cout > 256 || a.phases != 1 || a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.cout != 32 && (a.rgb_w || a.rgb_only)) return false;   // the fused ToRGB needs all channels in one workgroup
     if (a.splitk > 1) return false;
     // lean epilogue: bf16 NHWC vector stores, bias + (Leaky)ReLU * gain, optional fused ToRGB
     if (a.out_layout != VT_OUT_NHWC || a.out_f32 || !a.vec_store || a.resid || a.slope_vec || a.alpha_dev || a.post_relu) return false;
@@ -1981,7 +1986,9 @@ int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     args.splitk = 1;
     args.tiles_n = 1;
     args.tiles_m = a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16);
-    int blocks = args.tiles_m < 512 ? args.tiles_m : 512;   // persistent: 2 workgroups per CU
+    const int groups = a.cout / 32;                          // blockIdx.y: 32 output channels each
+    const int per_group = 512 / groups > 0 ? 512 / groups : 1;
+    int blocks = args.tiles_m < per_group ? args.tiles_m : per_group;   // persistent: 2 workgroups per CU in all
     if (const char* e = getenv("VT_C32_BLOCKS")) {          // tests: force several tiles per workgroup
         const int v = atoi(e);
         if (v > 0 && v < blocks) blocks = v;
@@ -1992,7 +1999,7 @@ int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     auto k = conv3x3_c32_kernel<bf16_t>;
 #endif
     (void)sizeof(T);
-    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    VT_LAUNCH(k, dim3((unsigned)blocks, (unsigned)groups), dim3(256), stream, args, g);
     return vt_check_launch("vt_conv2d(c32)");
 }
 

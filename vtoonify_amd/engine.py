@@ -144,8 +144,13 @@ class VToonifyEngine:
                 wsrc = sd[f"encoder.{bi}.{j}.weight"]
                 # input channels padded (zero weights) to the 128-byte K-step of the direct-to-LDS / patch kernels:
                 # the 32-channel stem output (encoder.0.0 -> encoder.0.2) otherwise drops to the register-staged loader
-                self.w[f"encoder.{bi}.{j}"] = K.pack_conv_weight(wsrc, cin_dst=self._kpad(wsrc.shape[1]) if j == 2 else None,
-                                                                 out_dtype=T)
+                # ... except behind a 32-channel stem in bf16: 32 -> 32 and 32 -> 128 are the persistent register-weight
+                # kernel's shapes (conv3x3_c32_kernel, 64-byte pixel rows), so neither the stem's input (22 -> 32 channels,
+                # zeros) nor its output (32, not 64) is padded to a K-step of zero weights
+                cin_dst = self._kpad(wsrc.shape[1]) if j == 2 else None
+                if self._stem32(bi):
+                    cin_dst = 32
+                self.w[f"encoder.{bi}.{j}"] = K.pack_conv_weight(wsrc, cin_dst=cin_dst, out_dtype=T)
         for ii in range(6):
             for nm in ("conv", "conv2"):
                 key = f"encoder.{self.n_down}.{ii}.{nm}"
@@ -192,6 +197,14 @@ class VToonifyEngine:
                     st = K.conv_weight_stream(wt)
                     if st is not None:
                         self._wstream[wt.data_ptr()] = st
+
+    def _stem32(self, bi: int) -> bool:
+        """Does encoder block `bi` run on 32-channel pixel rows (bf16, a stem of <= 32 inputs -> 32 -> 32k channels)?
+        VT_STEM32=0: the K-step-padded layout of the tile kernels (A/B)."""
+        sd = self.sd
+        w0, w2 = sd[f"encoder.{bi}.0.weight"], sd[f"encoder.{bi}.2.weight"]
+        return (bi == 0 and self.dtype == torch.bfloat16 and w0.shape[1] <= 32 and w0.shape[0] == 32 and
+                w2.shape[0] % 32 == 0 and w2.shape[0] <= 256 and os.environ.get("VT_STEM32", "1") != "0")
 
     def _kpad(self, c: int) -> int:
         """Channel count rounded up to the K-step of the LDS loaders (64 bf16 / 32 fp32 channels = 128 bytes)."""
@@ -459,9 +472,12 @@ class VToonifyEngine:
 
         # ---- content encoder (model/vtoonify.py:160-183, 226-242) -------------------
         cin0 = sd["encoder.0.0.weight"].shape[1]
-        x_nhwc = self._buf(plan, "x_nhwc", (B, H, W, _pad8(cin0)))
+        cin_p = 32 if self._stem32(0) else _pad8(cin0)
+        x_nhwc = self._buf(plan, "x_nhwc", (B, H, W, cin_p))
+        if cin_p != _pad8(cin0):
+            x_nhwc.zero_()          # the layout change writes pad8(cin0) channels per pixel: the rest stay zero
         plan.cin0 = cin0
-        cur, cc, h, w = x_nhwc, _pad8(cin0), H, W
+        cur, cc, h, w = x_nhwc, cin_p, H, W
         feats = []
         for bi in range(self.n_down):
             stride = 1 if bi == 0 else 2
@@ -472,7 +488,7 @@ class VToonifyEngine:
                 ho, wo = (h + 2 - 3) // st + 1, (w + 2 - 3) // st + 1
                 # the first conv of a block writes into a K-step-padded pixel stride (pad channels stay zero, the next
                 # conv's weights for them are zero too): only the 32-channel stem output actually grows (32 -> 64)
-                cs = self._kpad(co) if j == 0 else co
+                cs = self._kpad(co) if (j == 0 and not self._stem32(bi)) else co
                 out = self._buf(plan, f"enc{bi}.{j}", (B, ho, wo, cs))
                 if cs != co:
                     out.zero_()
