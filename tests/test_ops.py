@@ -1022,7 +1022,7 @@ def test_conv_transpose_blur_persistent_form(dev, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_transpose_blur_kernel(dev, dtype):
+def test_conv_transpose_blur_kernel(dev, dtype, monkeypatch):
     """vt_conv_desc.up_fir: conv_transpose2d(3x3, stride 2) on the matrix cores + the 4x4 FIR blur from LDS + bias
     + LeakyReLU in one kernel (the up-sampling StyledConv at the reference's MAC count, model.py:273-286), vs the
     oracle's conv_transpose2d -> upfirdn2d(pad (1,1)) -> fused_leaky_relu on the same rounded operands, and vs the
@@ -1036,7 +1036,8 @@ def test_conv_transpose_blur_kernel(dev, dtype):
     k1 = np.array([1, 3, 3, 1], np.float32)
     fir = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)       # make_kernel([1,3,3,1]) * factor^2 (model.py:66,192-198)
     for N, cin, H, W, cout, hint in [(2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 0),
-                                     (1, 5 * unit, 6, 9, 32, 16)]:   # 16-channel tiles, >= 4 chunks: double-buffered
+                                     (1, 5 * unit, 6, 9, 32, 16),    # 16-channel tiles, >= 4 chunks: double-buffered
+                                     (1, 2 * unit, 27, 15, 32, 32)]:  # two rows of tall tiles (44 output rows each)
         x = g.standard_normal((N, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
         b = g.standard_normal(cout).astype(np.float32)
@@ -1061,6 +1062,14 @@ def test_conv_transpose_blur_kernel(dev, dtype):
         out_w = torch.zeros_like(out)
         K.conv2d(**{**kw, "out": out_w, "tile_hint": 32 if (hint or 16) == 16 else 16})
         assert torch.equal(out_w, out), (N, cin, H, W, cout, hint)
+        if dtype == torch.bfloat16 and cin >= 2 * unit:      # ... and so do the tall tiles (24 x 16 quads, 8 waves)
+            monkeypatch.setenv("VT_UPBLUR_TALL", "1")
+            monkeypatch.setenv("VT_UPBLUR_DB", "99")
+            out_t = torch.zeros_like(out)
+            K.conv2d(**{**kw, "out": out_t, "tile_hint": 32})
+            monkeypatch.delenv("VT_UPBLUR_TALL")
+            monkeypatch.delenv("VT_UPBLUR_DB")
+            assert torch.equal(out_t, out), (N, cin, H, W, cout, "tall")
         # the polyphase form of the same layer (blur folded into four 3x3 filters)
         wpp = K.modulate_weight(T(w, dev), torch.ones(cin, device=dev), 1.0, False, fir=T(fir, dev), out_dtype=dtype)
         out2 = torch.zeros_like(out)

@@ -2040,6 +2040,20 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         const bool lb2 = !(le && le[0] == '0');
         if (t.bn == 32 && chunks == 1 && persist_min > 0 && tiles * vt_cdiv(a.coutT, 32) >= persist_min)
             return launch_upblur<T, 32, 12, 0, 1, 0>(a, stream);
+        {
+            // tall tiles (24 x 16 quads, 8 waves, one workgroup per CU) where the layer is bound by L2 -> LDS bytes -- four or
+            // more channel chunks -- and still gives every CU ~2 workgroups: 125 -> 100 us (512 -> 256) and 132 -> 119 us
+            // (256 -> 128) at 4 frames; 128 -> 64 loses (152 -> 162: two resident workgroups hide its blur phase better).
+            // Same bits as the 12-row tiles (tests/test_ops.py).
+            // VT_UPBLUR_TALL = minimum workgroup count of the tall form (0 = never; the tests pass 1 and a 2-chunk layer)
+            const char* te = getenv("VT_UPBLUR_TALL");
+            const int64_t tall_min = te ? atoll(te) : 448;
+            const int64_t wgs_tall = (int64_t)a.N * vt_cdiv(2 * a.H, 44) * vt_cdiv(2 * a.W, 28) * vt_cdiv(a.coutT, 32);
+            if constexpr (sizeof(T) == 2) {   // (the fp32 z tile of 47 x 31 pixels does not fit the LDS)
+                if (t.bn == 32 && !db && chunks >= (te ? 2 : 4) && tall_min > 0 && wgs_tall >= tall_min)
+                    return launch_upblur<T, 32, 24, 0, 0, 0, 8>(a, stream);
+            }
+        }
         if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1, 0, 0>(a, stream) : launch_upblur<T, 16, 12, 0, 0, 0>(a, stream);
         if (db) return launch_upblur<T, 32, 12, 1, 0, 0>(a, stream);
         return lb2 ? launch_upblur<T, 32, 12, 0, 0, 1>(a, stream) : launch_upblur<T, 32, 12, 0, 0, 0>(a, stream);

@@ -31,13 +31,17 @@ struct UpblurArgs {
     int skew;                 // VT_UPBLUR_SKEW experiment (0 = off)
 };
 
-template <typename T, int CN, int QY, int DB, int PERSIST, int LB2>
-__global__ void __launch_bounds__(256, LB2 ? 2 : 1)   // LB2: cap at 256 registers so that two 4-wave workgroups share a CU
+// NW = wavefronts (3 quad rows each at QY = 3 NW).  4: 12 x 16 quads, two workgroups per CU.  8 (QY = 24): 24 x 16 quads,
+// one workgroup per CU -- the 36 KB of weights a chunk brings in serve twice the pixels and the blur halo is recomputed
+// for 1.25x instead of 1.37x of the output: the deep levels are bound by L2 -> LDS bytes (609 MB at 4.4 TB/s = the 137 us
+// of the 512 -> 256 level at 4 frames), so bytes per MAC is what counts there.
+template <typename T, int CN, int QY, int DB, int PERSIST, int LB2, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, (LB2 && NW == 4) ? 2 : 1)   // LB2: cap at 256 registers so that two 4-wave workgroups share a CU
 conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VEC = 16 / ESZ;
     constexpr int BK = 8 * VEC;
-    constexpr int NW = 4;
+    constexpr int NT = NW * 64;                   // threads
     constexpr int QX = 16, TY = 2 * (QY - 2), TX = 2 * (QX - 2);
     constexpr int MF = QY / NW;                   // quad rows (MFMA fragments) per wave
     constexpr int TN = CN / 16;                   // channel fragments per class
@@ -139,9 +143,9 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 
     // ---- blur constants (phase 3), fixed for the workgroup ----------------------------------------------------
     constexpr int NV = CN / VEC;                 // 16-byte channel vectors per pixel
-    constexpr int GROUPS = 256 / (TX * NV) >= 1 ? 256 / (TX * NV) : 1;
+    constexpr int GROUPS = NT / (TX * NV) >= 1 ? NT / (TX * NV) : 1;
     constexpr int ROWS = TY / GROUPS;
-    static_assert(TX * NV <= 256 && TY % GROUPS == 0, "one thread per (column, channel vector, row group)");
+    static_assert(TX * NV <= NT && TY % GROUPS == 0, "one thread per (column, channel vector, row group)");
     float kx[4], ky[4], bv[VEC], gpos[VEC], gneg[VEC];   // act(v) * gain = v * (v > 0 ? gpos : gneg)
     const int qv = tid % NV, col = (tid / NV) % TX, grp = tid / (NV * TX);
     const int nch = n0 + qv * VEC;
@@ -389,7 +393,7 @@ static bool upblur_eligible(const ConvArgs& a, UpblurArgs& g, int ty, int tx) {
     return true;
 }
 
-template <typename T, int CN, int QY, int DB, int PERSIST, int LB2>
+template <typename T, int CN, int QY, int DB, int PERSIST, int LB2, int NW = 4>
 int launch_upblur(const ConvArgs& a, vt_stream stream) {
     UpblurArgs g;
     if (!upblur_eligible<T>(a, g, 2 * (QY - 2), 28)) {
@@ -419,7 +423,7 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
         const char* e = getenv("VT_UPBLUR_SKEW");
         g.skew = e ? atoi(e) : 0;
     }
-    auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST, LB2>;
-    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g);
+    auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST, LB2, NW>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(NW * 64), stream, args, g);
     return vt_check_launch("vt_conv2d(upblur)");
 }

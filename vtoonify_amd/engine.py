@@ -763,6 +763,8 @@ class VToonifyEngine:
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
+                if tile // 100000000 == 7 and os.environ.get("VT_RGB_FUSE_C64", "1") == "0":
+                    fuse_rgb = False   # A/B: the 64 -> 64 level's ToRGB as its own (streaming) launch
                 # the LAST level's activation feeds nothing but its ToRGB: with the fused epilogue on the persistent 32 -> 32
                 # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only).  VT_RGB_ONLY=0: A/B.
                 rgb_only = (fuse_rgb and lvl == 4 and tile // 100000000 == 3 and
