@@ -463,6 +463,67 @@ def wp_ref(w, dtype):
     return w if dtype == torch.float32 else torch.from_numpy(w).to(torch.bfloat16).float().numpy()
 
 
+def test_conv_batch_aware_tiles(dev, monkeypatch):
+    """Plan choices that look at the batch (vt_conv2d_tile, no compute on CPU): a batch that fills the GPU with
+    256-pixel x 128-channel patch tiles gets them -- where one frame alone takes 128 x 64 tiles of the same kernel the bits
+    are the same (checked on the GPU), where it takes the whole-K kernels the results agree to rounding and
+    VT_BATCH_EXACT=1 restores the per-image choice."""
+    import ctypes
+    from vtoonify_amd import _lib
+    lib = _lib.lib()
+
+    def code(N, cin, H, W, cout, stream=False, exact=None):
+        if exact is None:
+            monkeypatch.delenv("VT_BATCH_EXACT", raising=False)
+        else:
+            monkeypatch.setenv("VT_BATCH_EXACT", exact)
+        x = torch.zeros((1,), dtype=torch.bfloat16, device=dev)      # never dereferenced by the query
+        d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=H, out_w=W, weight=x, cout=cout, kh=3, kw=3,
+                             pad=1, out=x, ld_out=cout, dtype=K.VT_BF16)
+        if stream:
+            d.weight_stream = x.data_ptr()
+        d.splitk_ws, d.splitk_ws_bytes = x.data_ptr(), 1 << 40
+        return lib.vt_conv2d_tile(ctypes.byref(d))
+
+    assert code(1, 256, 128, 128, 256) == 101128064                    # one frame: 128 x 64 patch tiles, no K split
+    assert code(4, 256, 128, 128, 256) == 101256128                    # four: 256 x 128 tiles of the same kernel
+    assert code(4, 256, 128, 128, 256, exact="1") == 101256128         # (same bits: allowed under VT_BATCH_EXACT)
+    assert code(1, 512, 64, 64, 512, stream=True) // 100000000 in (4, 8)   # whole-K kernels for one frame ...
+    assert code(4, 512, 64, 64, 512, stream=True) == 101256128             # ... patch tiles for a batch that fills the GPU
+    assert code(4, 512, 64, 64, 512, stream=True, exact="1") // 100000000 in (4, 8)
+    assert code(4, 512, 32, 32, 512, stream=True) // 100000000 == 8    # the 32 x 32 trunk stays weight-stationary
+    monkeypatch.delenv("VT_BATCH_EXACT", raising=False)
+    if dev.type != "cuda":
+        return
+    # GPU: the 256 x 128 tiles of a batch against the same frames one at a time
+    g = np.random.default_rng(9)
+    for cin, H, W, cout, same_bits in ((256, 128, 128, 256, True), (512, 64, 64, 512, False)):
+        x = g.standard_normal((4, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), torch.bfloat16)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=torch.bfloat16)
+        wst = K.conv_weight_stream(wp)
+        ws = torch.zeros(64 << 20, dtype=torch.float32, device=dev)
+
+        def run(xb):
+            out = torch.zeros((xb.shape[0], H, W, cout), dtype=torch.bfloat16, device=dev)
+            d = K.make_conv_desc(src0=xb, c0=cin, ld0=cin, n=xb.shape[0], h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout,
+                                 kh=3, kw=3, pad=1, act=K.ACT_LRELU, out=out, ld_out=cout, dtype=K.VT_BF16, splitk_ws=ws)
+            if wst is not None:
+                d.weight_stream = wst.data_ptr()
+            assert lib.vt_conv2d(ctypes.byref(d), K._stream(xb)) == 0, lib.vt_last_error()
+            return out
+        full = run(xt)
+        alone = torch.cat([run(xt[i:i + 1].contiguous()) for i in range(4)])
+        if same_bits:
+            assert torch.equal(full, alone)
+        else:
+            assert rel_err(full.float().cpu().numpy(), alone.float().cpu().numpy()) < 4e-3
+            monkeypatch.setenv("VT_BATCH_EXACT", "1")
+            assert torch.equal(run(xt), alone)
+            monkeypatch.delenv("VT_BATCH_EXACT")
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

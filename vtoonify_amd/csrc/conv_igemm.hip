@@ -1796,6 +1796,11 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     auto ptiles = [&](int th, int n) {
         return (int64_t)vt_cdiv(a.Ho, th) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, n);
     };
+    // VT_BATCH_EXACT=1: no plan choice that makes a frame inside a batch differ (in rounding) from the frame alone
+    auto batch_exact = [] {
+        const char* be = getenv("VT_BATCH_EXACT");   // read per call: tests flip it
+        return be && be[0] == '1';
+    };
     GldsArgs g;
     if (hp != 2 && hbm == 0 && c32_eligible<T>(a, g)) {   // the 1024^2 level: persistent register-weight kernel
         t.kind = 3;
@@ -1832,6 +1837,20 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
                 const char* e = getenv("VT_FULLK_MAX_WGS");
                 return e && atoi(e) > 0 ? atoi(e) : 1024;
             }();
+            // A batch that fills the GPU with 256-pixel x 128-channel patch tiles (one 8-wave workgroup per CU, no K split) is
+            // better served by them: 512 -> 512 @64^2 111 -> 82 us, 1024 -> 512 @64^2 250 -> 161 us at 4 frames
+            // (profiles/r03_batch_tiles.txt).  The patch kernel sums K in another order than the whole-K kernels, so a frame
+            // inside such a batch equals the frame alone to rounding, not to the bit: VT_BATCH_EXACT=1 keeps the per-image
+            // choice (read per call).
+            const bool batch_patch = !hinted && hbm == 0 && hp == 0 && a.N > 1 && a.dil == 1 && a.coutT >= 128 && !a.tile_stats &&
+                                     !a.in_tile_stats && !a.stats_part && (int64_t)a.N * ptiles(16, 128) >= 256 &&
+                                     !batch_exact() && patch_eligible<T>(a, g);
+            if (batch_patch) {
+                t.kind = 1;
+                t.bm = 256, t.bn = 128;
+                t.splitk = 1;
+                return t;
+            }
             if (hinted || fk_mode >= 2 || (a.coutT >= 128 && wgs <= fk_max_wgs)) {
                 t.kind = 4;
                 t.bm = FK_TH * FK_TW;
@@ -1880,6 +1899,14 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             t.bm = 128, t.bn = 64;
         } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
             t.bm = 256, t.bn = 128;
+        } else if (a.dil == 1 && a.coutT >= 128 && (int64_t)a.N * ptiles(16, 128) >= 256 &&
+                   ((ptiles(8, 128) >= 192 && ptiles(8, 64) >= 384) || !batch_exact())) {
+            // a batch fills the GPU with the 256 x 128 tiles where one frame would not: 256 -> 256 @128^2 117 -> 92 us,
+            // 512 -> 256 @128^2 220 -> 169 us at 4 frames.  Where one frame alone takes the 128 x 64 tiles without a K split
+            // (the first pair of conditions) the sum order is the same and so are the bits (tests/test_ops.py); elsewhere this
+            // is a choice only a batch gets unless VT_BATCH_EXACT=1
+            t.bm = 256, t.bn = 128;
+            t.splitk = 1;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
             t.bm = 256, t.bn = 64;
         } else if (fullk > 0 && a.coutT >= 128 && a.coutT % 64 == 0 && ptiles(8, 128) < 192 && ptiles(4, 64) >= 96) {
