@@ -486,6 +486,17 @@ def main():
             f32["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows32[:4]]
             extras["fp32"] = f32
             del eng32
+        # the headline workload with plans from the per-image geometry only (VT_BATCH_EXACT=1: a frame inside a batch equals
+        # the frame alone bit for bit): fresh engine, the switch is read when its plans are built
+        if B > 1 and os.environ.get("VT_BATCH_EXACT") != "1":
+            os.environ["VT_BATCH_EXACT"] = "1"
+            try:
+                eng_x = VToonifyEngine(sd_dev, args.backbone, 256, dtype, dev)
+                extras["batch_exact"] = lanes_rate(B, H, W, 24, engine=eng_x,
+                                                   note="VT_BATCH_EXACT=1: no plan choice that depends on the batch's rounding")
+                del eng_x
+            finally:
+                del os.environ["VT_BATCH_EXACT"]
         torch.cuda.empty_cache()
         extras["op_surface"] = op_surface(dev)
 
@@ -585,6 +596,7 @@ def main():
                        "frames_per_step_per_gpu": B, "parallelism": f"frame-parallel x{ws}",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "frames_in_flight_per_gpu": lanes, "tile_hints": args.tile_hints or None,
+                       "plans": "per-image (VT_BATCH_EXACT=1)" if os.environ.get("VT_BATCH_EXACT") == "1" else "batch-aware",
                        "splitk_workgroup_target": int(os.environ.get("VT_SPLITK_WGS", "256")),
                        "weight_broadcast_s": t_bcast, "host": host,
                        "per_rank_frames_per_s": fps / ws},

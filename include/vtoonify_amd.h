@@ -194,6 +194,12 @@ typedef struct vt_conv_desc {
      * (model/stylegan/model.py:364-392, model/vtoonify.py:269-272): 67 MB per 1024^2 frame that the reference writes
      * and nobody reads.  Supported by the persistent 32 -> 32 kernel (KIND 3); VT_ERR_UNSUPPORTED elsewhere. */
     int32_t rgb_only;
+    /* ABI 4: != 0: the input is cat[src0, |src0 - src1|] (src1 = "other", c1 == c0): the operand of the Fusion gate's mask
+     * conv (model/vtoonify.py:125-126), formed in the loader; with in_scale / in_shift ([n][2 c0], e.g. from
+     * vt_instnorm_stats) the AdaIN affine is applied there too, so vt_affine_apply and its 2C-channel normalised copy are not
+     * needed.  Bit-identical to vt_affine_apply -> vt_conv2d.  Supported by the thin-output kernel (KIND 6: 3x3, pad 1,
+     * cout == 1); VT_ERR_UNSUPPORTED elsewhere. */
+    int32_t in_absdiff;
 } vt_conv_desc;
 
 int vt_conv2d(const vt_conv_desc* desc, vt_stream stream);

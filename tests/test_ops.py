@@ -271,6 +271,58 @@ def test_conv_thin_kernel(dev, dtype):
         assert e_new < t and e_old < t, (N, Cin, H, W, Cout, k, e_new, e_old)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_thin_gate_prologue(dev, dtype):
+    """vt_conv_desc.in_absdiff + in_scale / in_shift on the thin kernel: the Fusion gate's mask conv reads f_G and f_E, forms
+    cat[f_G, |f_G - f_E|] and applies the AdaIN affine in its loader (vtoonify.py:125-126) -- BIT-identical to
+    vt_affine_apply into a 2C-channel tensor followed by the plain conv; tile edges, batch 2, K-steps that do not divide
+    by the wavefronts; refused on the other kernels."""
+    import ctypes as C
+    from vtoonify_amd import _lib
+    lib = _lib.lib()
+    g = np.random.default_rng(41)
+    kstep = 16 if dtype == torch.float32 else 32
+    code = K.dt_code(dtype)
+    for (N, c, H, W) in ((1, 2 * kstep, 8, 8), (2, 3 * kstep, 11, 13), (1, 5 * kstep, 5, 20)):
+        fg = g.standard_normal((N, c, H, W)).astype(np.float32)
+        fe = g.standard_normal((N, c, H, W)).astype(np.float32)
+        w = (g.standard_normal((1, 2 * c, 3, 3)) / math.sqrt(18 * c)).astype(np.float32)
+        bias = T(g.standard_normal(1).astype(np.float32) * 0.1, dev)
+        sc = T((1 + 0.3 * g.standard_normal((N, 2 * c))).astype(np.float32), dev)
+        sh = T((0.3 * g.standard_normal((N, 2 * c))).astype(np.float32), dev)
+        fgt, fet = K.nchw_to_nhwc(T(fg, dev), dtype), K.nchw_to_nhwc(T(fe, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        # two launches: normalised copy, then the conv
+        nrm = torch.zeros((N, H, W, 2 * c), dtype=dtype, device=dev)
+        K.affine_apply(nrm, 2 * c, fgt, c, sc, sh, N, H * W, c, code, other=fet, ld_other=c)
+        ref = torch.zeros((N, 1, H, W), device=dev)
+        common = dict(n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=1, kh=3, kw=3, pad=1, bias=bias,
+                      act=K.ACT_RELU_TANH, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, dtype=code)
+        K.conv2d(src0=nrm, c0=2 * c, ld0=2 * c, out=ref, **common)
+        # one launch
+        out = torch.zeros_like(ref)
+        d = K.make_conv_desc(src0=fgt, c0=c, ld0=c, src1=fet, c1=c, ld1=c, in_scale=sc, in_shift=sh, in_absdiff=1, out=out,
+                             **common)
+        assert lib.vt_conv2d_tile(C.byref(d)) // 100000000 == 6
+        assert lib.vt_conv2d(C.byref(d), K._stream(out)) == 0, lib.vt_last_error()
+        assert float(ref.abs().max()) > 0.05 and torch.equal(out, ref), (N, c, H, W)
+        # the affine alone (one source) through the same loader
+        ref1, out1 = torch.zeros_like(ref), torch.zeros_like(ref)
+        nrm1 = torch.zeros((N, H, W, c), dtype=dtype, device=dev)
+        w1 = K.pack_conv_weight(T(w[:, :c].copy(), dev), out_dtype=dtype)
+        K.affine_apply(nrm1, c, fgt, c, sc[:, :c].contiguous(), sh[:, :c].contiguous(), N, H * W, c, code)
+        K.conv2d(src0=nrm1, c0=c, ld0=c, out=ref1, **{**common, "weight": w1})
+        K.conv2d(src0=fgt, c0=c, ld0=c, in_scale=sc[:, :c].contiguous(), in_shift=sh[:, :c].contiguous(), out=out1,
+                 **{**common, "weight": w1})
+        assert torch.equal(out1, ref1)
+    # three planar outputs (27 virtual channels) have no prologue instance: refused, not silently wrong
+    w3 = K.pack_conv_weight(T((g.standard_normal((3, 2 * c, 3, 3)) / 10).astype(np.float32), dev), out_dtype=dtype)
+    o3 = torch.zeros((N, 3, H, W), device=dev)
+    d = K.make_conv_desc(src0=fgt, c0=c, ld0=c, src1=fet, c1=c, ld1=c, in_absdiff=1, out=o3,
+                         **{**common, "weight": w3, "cout": 3, "bias": None})
+    assert lib.vt_conv2d(C.byref(d), K._stream(o3)) == 2   # VT_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("hint", [128128, 128064, 128032, 128016, 64064, 64128, 32064])
 def test_conv_every_tile(dev, hint):
     for dtype in (torch.float32, torch.bfloat16):

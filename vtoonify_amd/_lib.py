@@ -54,7 +54,7 @@ class ConvDesc(C.Structure):
         ("weight_stream", C.c_void_p),
         ("tile_stats", C.c_void_p), ("in_tile_stats", C.c_void_p), ("in_stats_dil", C.c_int32),
         ("in_gb", C.c_void_p), ("in_ld_gb", C.c_int32),
-        ("up_fir", C.c_void_p), ("pad_w_p1", C.c_int32), ("rgb_only", C.c_int32),
+        ("up_fir", C.c_void_p), ("pad_w_p1", C.c_int32), ("rgb_only", C.c_int32), ("in_absdiff", C.c_int32),
     ]
 
 

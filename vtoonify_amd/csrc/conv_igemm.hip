@@ -85,6 +85,7 @@ struct ConvArgs {
     int in_ld_gb;
     const float* up_fir;        // conv_transpose2d(stride 2) + blur form (conv_upblur.hpp) or NULL
     int rgb_only;               // vt_conv_desc.rgb_only: the C-channel output is not stored (fused ToRGB only)
+    int in_absdiff;             // vt_conv_desc.in_absdiff: input = cat[src0, |src0 - src1|] (thin kernel)
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
 };
 
@@ -2042,6 +2043,10 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                      a.coutT, t.bm, t.bn, t.splitk);
         return VT_ERR_UNSUPPORTED;
     }
+    if (a.in_absdiff && t.kind != 6) {
+        vt_set_error("vt_conv2d: in_absdiff needs the thin-output kernel (plan kind %d)", t.kind);
+        return VT_ERR_UNSUPPORTED;
+    }
     if (a.rgb_only && t.kind != 3) {
         vt_set_error("vt_conv2d: rgb_only needs the persistent 32 -> 32 kernel (plan kind %d)", t.kind);
         return VT_ERR_UNSUPPORTED;
@@ -2231,6 +2236,8 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.post_relu = d->post_relu ? 1 : 0;
     a.wstream = d->weight_stream;
     a.rgb_only = (d->rgb_only && d->rgb_weight) ? 1 : 0;
+    a.in_absdiff = d->in_absdiff ? 1 : 0;
+    VT_REQUIRE(!a.in_absdiff || (d->src1 && d->c1 == d->c0), "vt_conv2d: in_absdiff needs src1 with c1 == c0");
     a.tile_stats = (float*)d->tile_stats;
     a.in_tile_stats = (const float*)d->in_tile_stats;
     a.in_stats_dil = d->in_stats_dil > 0 ? d->in_stats_dil : 1;

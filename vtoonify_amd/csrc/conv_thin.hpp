@@ -27,19 +27,27 @@ constexpr int TH_PADC = 4;          // floats of padding per d row (LDS banks)
 template <typename T>
 static bool thin_eligible(const ConvArgs& a) {
     constexpr int KSTEP = 4 * (16 / (int)sizeof(T));
-    if (a.force_generic || a.transposed || a.in_scale || a.rgb_w || a.stats_part || a.tile_stats || a.in_tile_stats ||
-        a.up_fir || a.slope_vec)
+    if (a.force_generic || a.transposed || a.rgb_w || a.stats_part || a.tile_stats || a.in_tile_stats || a.up_fir || a.slope_vec)
         return false;
+    if (a.in_scale && !a.in_shift) return false;
+    if ((a.in_scale || a.in_absdiff) && !(a.taps == 9 && a.taps * a.coutT <= 16)) return false;   // the compiled prologue form
     if (a.out_layout != VT_OUT_NCHW || a.phases != 1 || a.stride != 1 || a.dil != 1) return false;
     if (!((a.taps == 9 && a.kw == 3 && a.pad == 1) || (a.taps == 1 && a.pad == 0))) return false;
     if (a.coutT < 1 || a.coutT > 3 || a.taps * a.coutT > TH_COLS) return false;
-    if (a.c1 != 0 || a.c0 % KSTEP != 0 || a.ld0 % (16 / (int)sizeof(T)) != 0) return false;
+    // one source, or the Fusion gate's cat[x, |x - other|] (vt_conv_desc.in_absdiff: src1 = other, c1 = c0)
+    if (a.in_absdiff ? (a.c1 != a.c0 || !a.src1 || a.ld1 % (16 / (int)sizeof(T)) != 0 || (uintptr_t)a.src1 % 16 != 0) : a.c1 != 0)
+        return false;
+    if (a.c0 % KSTEP != 0 || a.ld0 % (16 / (int)sizeof(T)) != 0) return false;
     if (a.Ho != a.H || a.Wo != a.W) return false;
     if ((uintptr_t)a.src0 % 16 != 0 || (uintptr_t)a.wgt % 16 != 0) return false;
     return (int64_t)a.N * a.H * a.W * a.ld0 * (int64_t)sizeof(T) < ((int64_t)1 << 40);
 }
 
-template <typename T, int KS, int NB>   // KS = 3 (3x3, pad 1) or 1 (1x1); NB = weight fragments (16 virtual channels each)
+// PRO: input prologue in the loader (the Fusion gate, model/vtoonify.py:125-126): the K range is cat[x, |x - other|]
+// (p.in_absdiff) and / or every in-image value goes through x' = x * in_scale[n][c] + in_shift[n][c], rounded to T like a
+// stored tensor -- the vt_affine_apply launch and its 2C-channel normalised copy (268 MB per 4-frame step at the 256^2 level)
+// fold into the conv that reads them.  Bit-identical to the two launches (same operations in the same order).
+template <typename T, int KS, int NB, bool PRO = false>   // KS = 3 (3x3, pad 1) or 1 (1x1); NB = weight fragments (16 virtual channels each)
 __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p) {
     constexpr int VEC = 16 / (int)sizeof(T);
     constexpr int KSTEP = 4 * VEC;                   // channels per MFMA K-step (lane group q owns VEC of them)
@@ -62,7 +70,8 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
 
     // this lane's pixel of every fragment (patch pixel f*16 + l15) -> element offset of its channel group, or -1
     const T* src = (const T*)p.src0;
-    int64_t poff[NF];
+    const T* oth = (const T*)p.src1;
+    int64_t poff[NF], qoff[PRO ? NF : 1];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int pp = f * 16 + l15;
@@ -70,6 +79,7 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
         const int iy = y0 + py - (KS / 2), ix = x0 + px - (KS / 2);
         const bool in = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         poff[f] = in ? ((int64_t)(img * p.H + iy) * p.W + ix) * p.ld0 + q * VEC : -1;
+        if (PRO) qoff[f] = in ? ((int64_t)(img * p.H + iy) * p.W + ix) * p.ld1 + q * VEC : -1;
     }
     // this lane's weight row of both fragments: virtual channel v = b*16 + l15 = tap * cout + co
     const T* wg = (const T*)p.wgt;
@@ -90,7 +100,8 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
     const u128 zero = u128{0u, 0u, 0u, 0u};
     const int nk = p.cin / KSTEP;
     for (int k0 = wave; k0 < nk; k0 += TH_NW * UNR) {
-        u128 fa[UNR][NF], fw[UNR][NB];
+        u128 fa[UNR][NF], fw[UNR][NB], fo[PRO ? UNR : 1][PRO ? NF : 1];
+        float scv[PRO ? UNR : 1][VEC], shv[PRO ? UNR : 1][VEC];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int ks = k0 + u * TH_NW;
@@ -99,9 +110,50 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
             // (predicated loads are right HERE: hipcc batches them -- all NF * UNR are issued before the first wait -- and dead
             // lanes fetch nothing; the unconditional-at-a-clamped-offset form measured 124 -> 145 us over the 7 launches)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
+            for (int f = 0; f < NF; ++f) {
+                if (!PRO) {
+                    fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
+                } else {
+                    const bool second = p.in_absdiff && kb >= p.c0;     // wave-uniform: the |x - other| half of the K range
+                    const int kc = second ? kb - p.c0 : kb;
+                    fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kc) : zero;
+                    fo[u][f] = (live && second && qoff[f] >= 0) ? ld128(oth + qoff[f] + kc) : zero;
+                }
+            }
+            if (PRO && p.in_scale) {   // this lane's VEC channels of the K-step: one table row serves all pixel fragments
+                const int so = img * p.cin + (live ? ks : k0) * KSTEP + q * VEC;
+#pragma unroll
+                for (int i = 0; i < VEC; i += 4) {
+                    unpack16<float>(ld128(p.in_scale + so + i), scv[u] + i);
+                    unpack16<float>(ld128(p.in_shift + so + i), shv[u] + i);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+        }
+        if (PRO) {   // the prologue on the fetched fragments (vt_affine_apply's arithmetic: |a - b|, then mul, then add, then round)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ks = k0 + u * TH_NW;
+                const bool second = p.in_absdiff && ks < nk && ks * KSTEP >= p.c0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (!(ks < nk && poff[f] >= 0)) continue;   // padding stays zero: it pads the NORMALISED tensor
+                    float v[VEC];
+                    unpack16<T>(fa[u][f], v);
+                    if (second) {
+                        float g[VEC];
+                        unpack16<T>(fo[u][f], g);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] = fabsf(v[i] - g[i]);
+                    }
+                    if (p.in_scale) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[i] = v[i] * scv[u][i] + shv[u][i];
+                    }
+                    fa[u][f] = pack16<T>(v);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -155,7 +207,14 @@ int launch_thin(const ConvArgs& a, vt_stream stream) {
         return VT_ERR_ARG;
     }
     const bool two = a.taps * a.coutT > 16;
-    if (a.taps == 9 && two) {
+    if (a.in_scale || a.in_absdiff) {   // the loader prologue: only the Fusion gate's shape is compiled (3x3, <= 16 virtual channels)
+        if (a.taps != 9 || two) {
+            vt_set_error("vt_conv2d: in_scale / in_absdiff on a thin conv need a 3x3 kernel with 9 * cout <= 16");
+            return VT_ERR_UNSUPPORTED;
+        }
+        auto k = conv_thin_kernel<T, 3, 1, true>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
+    } else if (a.taps == 9 && two) {
         auto k = conv_thin_kernel<T, 3, 2>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
     } else if (a.taps == 9) {

@@ -689,18 +689,27 @@ class VToonifyEngine:
                                     {"name": "fusion_gate", "kernel": "fusion_gate", "flops": 2 * B * hw * 2 * co * 9,
                                      "join": True, "bytes": B * hw * (2 * co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                     else:
-                        if not fus_plane:
-                            nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                            ops.append((lib.vt_affine_apply,
-                                        (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
-                                         C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
-                                         B, hw, co, dt),
-                                        {"name": "affine", "kernel": "affine_apply", "flops": 0,
-                                         "bytes": 4 * B * hw * co * self.esz}))
-                        self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, n=B, h=h, w=w, out_h=h, out_w=w,
-                                      weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1, kh=3, kw=3, pad=1,
-                                      bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH, out=mask, ld_out=0,
-                                      out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                        mask_kw = dict(n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1,
+                                       kh=3, kw=3, pad=1, bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH,
+                                       out=mask, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                        # the mask conv forms cat[f_G, |f_G - f_E|] and applies the AdaIN affine in its loader
+                        # (vt_conv_desc.in_absdiff + in_scale / in_shift: bit-identical to vt_affine_apply -> conv, without
+                        # the launch and the 2C-channel normalised copy).  VT_GATE_LOADER=0: the two launches (A/B)
+                        gate_kw = dict(src0=out, c0=co, ld0=co, src1=f_e, c1=co, ld1=co, in_scale=sc, in_shift=sh, in_absdiff=1)
+                        in_loader = (not fus_plane and os.environ.get("VT_GATE_LOADER", "1") != "0" and
+                                     self._conv_kind(**gate_kw, **mask_kw) == 6)
+                        if in_loader:
+                            self._op_conv(ops, plan, **gate_kw, **mask_kw)
+                        else:
+                            if not fus_plane:
+                                nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                                ops.append((lib.vt_affine_apply,
+                                            (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                             C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()),
+                                             C.c_void_p(sh.data_ptr()), B, hw, co, dt),
+                                            {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                             "bytes": 4 * B * hw * co * self.esz}))
+                            self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, **mask_kw)
                     plan.masks.append(mask)
                 if not (self.dual and self.fuse_gate):
                     ops.append((lib.vt_fusion_pack,

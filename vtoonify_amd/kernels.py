@@ -95,7 +95,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
                    alpha_dev=None, resid=None, ld_res=0, out_layout=OUT_NHWC, out_dtype=None,
                    tile_hint=0, splitk_ws=None, slope_vec=None, rgb_weight=None, rgb_bias=None, rgb_resid=None,
                    rgb_out=None, stats_part=None, post_relu=0, weight_stream=None, tile_stats=None,
-                   in_tile_stats=None, in_stats_dil=1, in_gb=None, in_ld_gb=0, up_fir=None, pad_w=None, rgb_only=0) -> ConvDesc:
+                   in_tile_stats=None, in_stats_dil=1, in_gb=None, in_ld_gb=0, up_fir=None, pad_w=None, rgb_only=0, in_absdiff=0) -> ConvDesc:
     """Fill a vt_conv_desc.  Pointers may be tensors or raw ints (sub-views: data_ptr()+offset)."""
     d = ConvDesc()
     d.src0, d.src1 = _ptr(src0), _ptr(src1)
@@ -125,6 +125,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
     d.up_fir = _ptr(up_fir)
     d.pad_w_p1 = 0 if pad_w is None else int(pad_w) + 1
     d.rgb_only = int(rgb_only)
+    d.in_absdiff = int(in_absdiff)
     if splitk_ws is not None:  # fp32 workspace tensor enabling split-K (see vt_conv2d_ws_bytes)
         d.splitk_ws, d.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     return d
