@@ -232,6 +232,39 @@ def test_config3_batch4_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_headline_batch4_vs_oracle(monkeypatch):
+    """The bench's headline step: D, 4 frames of 22x256x256 per call, bf16 -- the batch size at which the plans look at the
+    batch (256 x 128 patch tiles for the 64^2 / 128^2 convs).  Every frame against the oracle; against the
+    same frames one per call (to bf16 rounding by default, bit for bit under VT_BATCH_EXACT=1)."""
+    from oracle import vtoonify_oracle as O
+    from vtoonify_amd import _lib
+    from vtoonify_amd.engine import VToonifyEngine
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    sd = synth.synth_state_dict(load_keys("D"), 0)
+    x = synth.synth_frames(4, 256, 256, seed=77)
+    s = synth.synth_style(seed=17)
+    old = O.set_backend("torch")
+    try:
+        ref = np.concatenate([O.vtoonify_forward(synth.to_numpy_sd(sd), x[i:i + 1].numpy(), s.numpy(), 0.5,
+                                                 "dualstylegan") for i in range(4)], 0)
+    finally:
+        O.set_backend(old)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    xd, sdv = x.to(dev), s.to(dev)
+    eng = VToonifyEngine(sdd, "dualstylegan", 256, torch.bfloat16, dev)
+    y = eng.forward(xd, sdv.repeat(4, 1, 1), 0.5).clone()
+    check(y, ref, torch.bfloat16, "D 4x(256,256) batch-aware plans")
+    alone = torch.cat([eng.forward(xd[i:i + 1].contiguous(), sdv, 0.5).clone() for i in range(4)])
+    # two bf16 evaluations of the same frame that sum three convs in different orders: they differ like either differs from
+    # the fp32 oracle (every activation downstream is rounded to bf16 again), so the same bars apply
+    check(y, alone.float().cpu().numpy(), torch.bfloat16, "D 4x(256,256) batch of 4 vs one frame per call")
+    monkeypatch.setenv("VT_BATCH_EXACT", "1")
+    eng_x = VToonifyEngine(sdd, "dualstylegan", 256, torch.bfloat16, dev)
+    assert torch.equal(eng_x.forward(xd, sdv.repeat(4, 1, 1), 0.5), alone)
+
+
+@pytest.mark.gpu
 def test_full_size_properties():
     """Size-independent properties at 1536x1536 output and at the demo's 360x400 crop."""
     from vtoonify_amd import _lib
