@@ -461,6 +461,8 @@ def main():
                 extras["batch4"] = lanes_rate(4, H, W, 24)
             if B != 1:   # one frame per step (round 2's headline workload), same frames in flight
                 extras["batch1"] = lanes_rate(1, H, W, 60)
+            if B < 16:  # what a caller gets from a larger --batch_size (style_transfer.py:35): 16 frames per step, 2 steps in flight
+                extras["batch16"] = lanes_rate(16, H, W, 8, n_lanes=2)
             extras["config3"] = lanes_rate(4, 144, 256, max(8, 240 // ws))
             # BASELINE config 5: 1536x1536 output and the demo's nominal non-square, non-power-of-two crop
             # (vtoonify_model.py:250), VToonify-D, one frame per step

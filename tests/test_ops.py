@@ -1123,15 +1123,16 @@ def test_conv_transpose_blur_persistent_form(dev, dtype, monkeypatch):
     xt = K.nchw_to_nhwc(T(x, dev), dtype)
     wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
     outs = []
-    for persist in ("0", "1"):
-        monkeypatch.setenv("VT_UPBLUR_PERSIST", persist)
+    for persist in ("0", "1", "p8"):
+        monkeypatch.setenv("VT_UPBLUR_PERSIST", "0" if persist == "p8" else persist)
+        monkeypatch.setenv("VT_UPBLUR_P8", "1" if persist == "p8" else "0")   # 16 x 16 quads, 8 waves (bf16 only)
         monkeypatch.setenv("VT_UPBLUR_WGS", "5")
         out = torch.zeros((N, 2 * H, 2 * W, cout), dtype=dtype, device=dev)
         K.conv2d(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
                  bias=T(g.standard_normal(cout).astype(np.float32) * 0 + 0.1, dev), act=K.ACT_LRELU, gain=2 ** 0.5,
                  out=out, ld_out=cout, dtype=K.dt_code(dtype), up_fir=fir, tile_hint=32)
         outs.append(out.float().cpu().numpy())
-    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -2070,6 +2070,17 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         // and 54 vs 77 us on the 256^2 / 512^2-pixel levels; VT_UPBLUR_LB2=0 for the uncapped build
         const char* le = getenv("VT_UPBLUR_LB2");
         const bool lb2 = !(le && le[0] == '0');
+        if constexpr (sizeof(T) == 2) {
+            // single-chunk layers (the 1024^2 level) with >= 4 tiles per CU: persistent 8-wave workgroups on 16 x 16-quad tiles
+            // -- the 36 KB of weights stay in LDS instead of being re-fetched by every tile (more than the tile's 28 KB
+            // patch), the next patch flies during the blur, 8 waves keep the CU as busy as two 4-wave workgroups did.
+            // 264 -> 218 us at 4 frames (the 4-wave persistent form of round 2 lost to two plain workgroups per CU: 277).
+            // Same bits (tile shape only; tests/test_ops.py).  VT_UPBLUR_P8=0 / 1: never / always
+            const char* p8 = getenv("VT_UPBLUR_P8");
+            const int64_t tiles8 = (int64_t)a.N * vt_cdiv(2 * a.H, 28) * vt_cdiv(2 * a.W, 28) * vt_cdiv(a.coutT, 32);
+            const bool on = p8 ? p8[0] == '1' : tiles8 >= 1024;
+            if (on && t.bn == 32 && chunks == 1) return launch_upblur<T, 32, 16, 0, 1, 0, 8>(a, stream);
+        }
         if (t.bn == 32 && chunks == 1 && persist_min > 0 && tiles * vt_cdiv(a.coutT, 32) >= persist_min)
             return launch_upblur<T, 32, 12, 0, 1, 0>(a, stream);
         {
