@@ -1266,21 +1266,21 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         const PatchRows<TW> rowmap{img, y0, x0, p.Ho, p.Wo};
         const int HoWo = p.Ho * p.Wo;
-        // the up-sampled skip this tile adds to: fetched NOW so the loads fly during the 9 taps
-        float rsd[TM][3];
-        if (rgbf && p.rgb_resid && q == 0 && p.dbg != 2) {
+        // the up-sampled skip this tile adds to: fetched NOW so the loads fly during the 9 taps.  Lane (q, l15) finishes
+        // the ToRGB of tile row q of its wave (TM == 4 rows, 4 lane groups; see the reduce-scatter in the epilogue): three
+        // 256-byte loads and stores per wave and tile instead of twelve 64-byte ones
+        static_assert(TM == 4, "one tile row per lane group");
+        float rsd[3] = {0.0f, 0.0f, 0.0f};
+        const int m_rgb = rowmap(wm * (TM * 16) + q * 16 + l15);
+        int64_t o_rgb = 0;
+        {
+            const int mm = m_rgb < 0 ? 0 : m_rgb;
+            const int im = mm / HoWo;
+            o_rgb = (int64_t)im * 3 * HoWo + (mm - im * HoWo);
+        }
+        if (rgbf && p.rgb_resid && p.dbg != 2) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
-                const int mm = m < 0 ? 0 : m;
-                const int im = mm / HoWo;
-                const int64_t o0 = (int64_t)im * 3 * HoWo + (mm - im * HoWo);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) rsd[a][j] = p.rgb_resid[o0 + (int64_t)j * HoWo];
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) rsd[a][0] = rsd[a][1] = rsd[a][2] = 0.0f;
+            for (int j = 0; j < 3; ++j) rsd[j] = p.rgb_resid[o_rgb + (int64_t)j * HoWo];
         }
         f32x4 acc[TM][TN];
 #pragma unroll
@@ -1308,6 +1308,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         // bias + LeakyReLU * gain -> bf16 NHWC (8-byte stores), optional fused ToRGB
         {
             const float ga = p.gain_alpha;
+            float rp[TM][3];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
@@ -1332,19 +1333,31 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                 }
                 // one 16-byte store per lane: the four lane groups write the pixel's 64 bytes
                 if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + cg + q * 8, pack16<bf16_t>(f));
-                if (rgbf) {
+                rp[a][0] = r0; rp[a][1] = r1; rp[a][2] = r2;
+            }
+            if (rgbf) {
+                // reduce-scatter over the four lane groups (each holds 8 of a pixel's 32 channels, for all 4 tile rows): after
+                // the exchange with lane + 32 a lane holds two rows summed over two groups, after the one with lane + 16 ONE
+                // row -- row q -- summed over all four: 9 cross-lane moves instead of 24, and every lane has a pixel to write
+                const bool hi = q >= 2, odd = (q & 1) != 0;
+                float rr[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float keep_a = hi ? rp[2][j] : rp[0][j], keep_b = hi ? rp[3][j] : rp[1][j];
+                    const float send_a = hi ? rp[0][j] : rp[2][j], send_b = hi ? rp[1][j] : rp[3][j];
                     if (p.dbg != 3) {
-                    r0 += __shfl_xor(r0, 16, 64); r0 += __shfl_xor(r0, 32, 64);
-                    r1 += __shfl_xor(r1, 16, 64); r1 += __shfl_xor(r1, 32, 64);
-                    r2 += __shfl_xor(r2, 16, 64); r2 += __shfl_xor(r2, 32, 64);
+                        keep_a += __shfl_xor(send_a, 32, 64);
+                        keep_b += __shfl_xor(send_b, 32, 64);
                     }
-                    if (q == 0 && m >= 0 && (p.dbg != 1 || r0 == 123.456f)) {
-                        const int im = m / HoWo;
-                        const int64_t o0 = (int64_t)im * 3 * HoWo + (m - im * HoWo);
-                        p.rgb_out[o0] = r0 + rb0 + rsd[a][0];
-                        p.rgb_out[o0 + HoWo] = r1 + rb1 + rsd[a][1];
-                        p.rgb_out[o0 + 2 * (int64_t)HoWo] = r2 + rb2 + rsd[a][2];
-                    }
+                    float keep = odd ? keep_b : keep_a;
+                    const float send = odd ? keep_a : keep_b;
+                    if (p.dbg != 3) keep += __shfl_xor(send, 16, 64);
+                    rr[j] = keep;
+                }
+                if (m_rgb >= 0 && (p.dbg != 1 || rr[0] == 123.456f)) {
+                    p.rgb_out[o_rgb] = rr[0] + rb0 + rsd[0];
+                    p.rgb_out[o_rgb + HoWo] = rr[1] + rb1 + rsd[1];
+                    p.rgb_out[o_rgb + 2 * (int64_t)HoWo] = rr[2] + rb2 + rsd[2];
                 }
             }
         }
