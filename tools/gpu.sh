@@ -12,7 +12,7 @@
 #   smoke        __graft_entry__.smoke()
 #   conv ARGS    tools/conv_bench.py ARGS   (quote ARGS as one word, e.g. "--stream --only res --batch 4")
 #   op           tools/op_bench.py bf16 + fp32
-#   sh CMD       arbitrary command (one word)
+#   sh CMD       arbitrary command (one word), e.g. "bash tools/ab.sh adain" (the A/B experiments of round 3)
 TAG=${1:-r03}; shift
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
