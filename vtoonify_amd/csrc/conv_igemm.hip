@@ -2071,9 +2071,10 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         // double-buffered chunks (one workgroup per CU) only pay on the 16-channel tiles of the deepest layer
         // (33 vs 37 us); the 32-channel tiles run single-stage with two workgroups per CU (44 vs 51 us at 512->256)
         const char* de = getenv("VT_UPBLUR_DB");    // A/B: minimum chunk count of the double-buffered form
-        // ... and on 32-channel tiles when all workgroups are resident at once anyway (<= 512: 81 vs 86 us at 4 frames)
+        // ... and on 32-channel tiles of launches of at most three rounds of one workgroup per CU (the deepest level at 4 frames:
+        // 768 workgroups, 81 vs 85 us)
         const int64_t wgs_all = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28) * vt_cdiv(a.coutT, t.bn);
-        const bool db = de ? chunks >= atoi(de) : (chunks >= 4 && (t.bn == 16 || wgs_all <= 512));
+        const bool db = de ? chunks >= atoi(de) : (chunks >= 4 && (t.bn == 16 || wgs_all <= 768));
         // single-chunk layers with many tiles per CU (the 1024^2 level): persistent workgroups, resident weights.
         // VT_UPBLUR_PERSIST = minimum number of workgroups for the persistent form (0 = never; tests use 1)
         const char* pe = getenv("VT_UPBLUR_PERSIST");
