@@ -232,7 +232,8 @@ def test_config3_batch4_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_headline_batch4_vs_oracle(monkeypatch):
+@pytest.mark.parametrize("hw", [(256, 256), (144, 200)])   # the headline; a size whose 72x100 level has ragged 256-pixel tiles
+def test_headline_batch4_vs_oracle(monkeypatch, hw):
     """The bench's headline step: D, 4 frames of 22x256x256 per call, bf16 -- the batch size at which the plans look at the
     batch (256 x 128 patch tiles for the 64^2 / 128^2 convs).  Every frame against the oracle; against the
     same frames one per call (to bf16 rounding by default, bit for bit under VT_BATCH_EXACT=1)."""
@@ -242,7 +243,7 @@ def test_headline_batch4_vs_oracle(monkeypatch):
     _lib.use_library(_lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
     sd = synth.synth_state_dict(load_keys("D"), 0)
-    x = synth.synth_frames(4, 256, 256, seed=77)
+    x = synth.synth_frames(4, hw[0], hw[1], seed=77)
     s = synth.synth_style(seed=17)
     old = O.set_backend("torch")
     try:
@@ -254,11 +255,11 @@ def test_headline_batch4_vs_oracle(monkeypatch):
     xd, sdv = x.to(dev), s.to(dev)
     eng = VToonifyEngine(sdd, "dualstylegan", 256, torch.bfloat16, dev)
     y = eng.forward(xd, sdv.repeat(4, 1, 1), 0.5).clone()
-    check(y, ref, torch.bfloat16, "D 4x(256,256) batch-aware plans")
+    check(y, ref, torch.bfloat16, f"D 4x{hw} batch-aware plans")
     alone = torch.cat([eng.forward(xd[i:i + 1].contiguous(), sdv, 0.5).clone() for i in range(4)])
     # two bf16 evaluations of the same frame that sum three convs in different orders: they differ like either differs from
     # the fp32 oracle (every activation downstream is rounded to bf16 again), so the same bars apply
-    check(y, alone.float().cpu().numpy(), torch.bfloat16, "D 4x(256,256) batch of 4 vs one frame per call")
+    check(y, alone.float().cpu().numpy(), torch.bfloat16, f"D 4x{hw} batch of 4 vs one frame per call")
     monkeypatch.setenv("VT_BATCH_EXACT", "1")
     eng_x = VToonifyEngine(sdd, "dualstylegan", 256, torch.bfloat16, dev)
     assert torch.equal(eng_x.forward(xd, sdv.repeat(4, 1, 1), 0.5), alone)

@@ -1914,11 +1914,13 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
             t.bm = 256, t.bn = 128;
         } else if (a.dil == 1 && a.coutT >= 128 && (int64_t)a.N * ptiles(16, 128) >= 256 &&
-                   ((ptiles(8, 128) >= 192 && ptiles(8, 64) >= 384) || !batch_exact())) {
+                   ((ptiles(8, 128) >= 192 && ptiles(8, 64) >= 384 && !a.rgb_w) || !batch_exact())) {
             // a batch fills the GPU with the 256 x 128 tiles where one frame would not: 256 -> 256 @128^2 117 -> 92 us,
             // 512 -> 256 @128^2 220 -> 169 us at 4 frames.  Where one frame alone takes the 128 x 64 tiles without a K split
             // (the first pair of conditions) the sum order is the same and so are the bits (tests/test_ops.py); elsewhere this
-            // is a choice only a batch gets unless VT_BATCH_EXACT=1
+            // is a choice only a batch gets unless VT_BATCH_EXACT=1.  (A conv asked to fuse its ToRGB is "elsewhere": whether the
+            // tile holds all channels decides whether the caller fuses at all, and the fused epilogue reads the activations
+            // before they are rounded to the storage type.)
             t.bm = 256, t.bn = 128;
             t.splitk = 1;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
