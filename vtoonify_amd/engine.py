@@ -516,8 +516,8 @@ class VToonifyEngine:
         # per-tile {mean, M2} records with its output, the consumer normalises its input patch in LDS -- no
         # statistics launch, no normalisation launch, no normalised copy of the tensor (12 AdaINs per frame)
         fuse_adain = False
-        # VT_ADAIN: "plane" (default) = one vt_instnorm_plane launch per AdaIN (statistics + affine from registers, ~4 us on
-        # a quarter of the GPU) between plain convs; "fused" = round 2's tile records + in-LDS rewrite inside the whole-K convs
+        # VT_ADAIN: "plane" (default) = one vt_instnorm_plane launch per AdaIN (statistics + affine from registers: a 10 us
+        # latency chain on a quarter of the CUs, which the other frames in flight fill) between plain convs; "fused" = round 2's tile records + in-LDS rewrite inside the whole-K convs
         # (no extra launch, but +6.5 us in the producer and +17 us in the consumer of conv_fullkw_kernel, which owns every CU
         # it runs on: profiles/r03_adain_ab.txt); anything else = the chunk-record path below.
         adain_mode = os.environ.get("VT_ADAIN", "plane")
