@@ -99,68 +99,106 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
 
     const u128 zero = u128{0u, 0u, 0u, 0u};
     const int nk = p.cin / KSTEP;
-    for (int k0 = wave; k0 < nk; k0 += TH_NW * UNR) {
-        u128 fa[UNR][NF], fw[UNR][NB], fo[PRO ? UNR : 1][PRO ? NF : 1];
-        float scv[PRO ? UNR : 1][VEC], shv[PRO ? UNR : 1][VEC];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int ks = k0 + u * TH_NW;
-            const bool live = ks < nk;
-            const int kb = (live ? ks : k0) * KSTEP;
-            // (predicated loads are right HERE: hipcc batches them -- all NF * UNR are issued before the first wait -- and dead
-            // lanes fetch nothing; the unconditional-at-a-clamped-offset form measured 124 -> 145 us over the 7 launches)
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                if (!PRO) {
-                    fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
-                } else {
-                    const bool second = p.in_absdiff && kb >= p.c0;     // wave-uniform: the |x - other| half of the K range
-                    const int kc = second ? kb - p.c0 : kb;
-                    fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kc) : zero;
-                    fo[u][f] = (live && second && qoff[f] >= 0) ? ld128(oth + qoff[f] + kc) : zero;
-                }
-            }
-            if (PRO && p.in_scale) {   // this lane's VEC channels of the K-step: one table row serves all pixel fragments
-                const int so = img * p.cin + (live ? ks : k0) * KSTEP + q * VEC;
-#pragma unroll
-                for (int i = 0; i < VEC; i += 4) {
-                    unpack16<float>(ld128(p.in_scale + so + i), scv[u] + i);
-                    unpack16<float>(ld128(p.in_shift + so + i), shv[u] + i);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
-        }
-        if (PRO) {   // the prologue on the fetched fragments (vt_affine_apply's arithmetic: |a - b|, then mul, then add, then round)
+    if constexpr (!PRO) {
+        for (int k0 = wave; k0 < nk; k0 += TH_NW * UNR) {
+            u128 fa[UNR][NF], fw[UNR][NB];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ks = k0 + u * TH_NW;
-                const bool second = p.in_absdiff && ks < nk && ks * KSTEP >= p.c0;
+                const bool live = ks < nk;
+                const int kb = (live ? ks : k0) * KSTEP;
+                // (predicated loads are right HERE: hipcc batches them -- all NF * UNR are issued before the first wait -- and
+                // dead lanes fetch nothing; the unconditional-at-a-clamped-offset form measured 124 -> 145 us over the 7 launches)
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    if (!(ks < nk && poff[f] >= 0)) continue;   // padding stays zero: it pads the NORMALISED tensor
-                    float v[VEC];
-                    unpack16<T>(fa[u][f], v);
-                    if (second) {
-                        float g[VEC];
-                        unpack16<T>(fo[u][f], g);
+                for (int f = 0; f < NF; ++f) fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[i] = fabsf(v[i] - g[i]);
-                    }
-                    if (p.in_scale) {
+                for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+            }
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[i] = v[i] * scv[u][i] + shv[u][i];
-                    }
-                    fa[u][f] = pack16<T>(v);
-                }
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) Mma<T>::run(acc[f][b], fw[u][b], fa[u][f]);
             }
         }
+    } else {
+        // Prologue form.  A wave still takes K-steps wave, wave + 4, ... in increasing order (the order of the plain form: same
+        // bits), but in two loops: the x half of the K range with 2 steps in flight, the |x - other| half -- two operands per
+        // fragment -- with one: the registers of the larger loop (~170), not of both at once (330 as one loop: one wave per
+        // SIMD and 110 us at the 256^2 level).
+        const int nk0 = p.in_absdiff ? p.c0 / KSTEP : nk;   // K-steps of the first half
+        auto affine = [&](u128& frag, bool ok, const float* sc, const float* sh, const u128* og) {
+            if (!ok) return;                                  // padding stays zero: it pads the NORMALISED tensor
+            float v[VEC];
+            unpack16<T>(frag, v);
+            if (og) {
+                float g[VEC];
+                unpack16<T>(*og, g);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+                for (int i = 0; i < VEC; ++i) v[i] = fabsf(v[i] - g[i]);
+            }
+            if (p.in_scale) {                                 // vt_affine_apply's arithmetic: mul, then add, then round
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = v[i] * sc[i] + sh[i];
+            }
+            frag = pack16<T>(v);
+        };
+        auto table = [&](int ks, float* sc, float* sh) {      // this lane's VEC channels of the K-step: one row serves all fragments
+            if (!p.in_scale) return;
+            const int so = img * p.cin + ks * KSTEP + q * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; i += 4) {
+                unpack16<float>(ld128(p.in_scale + so + i), sc + i);
+                unpack16<float>(ld128(p.in_shift + so + i), sh + i);
+            }
+        };
+        constexpr int U1 = 2;
+        int k0 = wave;
+        for (; k0 < nk0; k0 += TH_NW * U1) {
+            u128 fa[U1][NF], fw[U1][NB];
+            float scv[U1][VEC], shv[U1][VEC];
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                const int ks = k0 + u * TH_NW;
+                const bool live = ks < nk0;
+                const int kb = (live ? ks : k0) * KSTEP;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fa[u][f] = (live && poff[f] >= 0) ? ld128(src + poff[f] + kb) : zero;
+                table(live ? ks : k0, scv[u], shv[u]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < U1; ++u) {
+                const bool live = k0 + u * TH_NW < nk0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) affine(fa[u][f], live && poff[f] >= 0, scv[u], shv[u], nullptr);
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) Mma<T>::run(acc[f][b], fw[u][b], fa[u][f]);
+            }
+        }
+        // this wave's first K-step of the second half: the smallest ks >= nk0 with ks = wave (mod 4)
+        for (int ks = nk0 + ((wave - nk0) % TH_NW + TH_NW) % TH_NW; ks < nk; ks += TH_NW) {
+            u128 fa[NF], fo[NF], fw[NB];
+            float scv[VEC], shv[VEC];
+            const int kb = ks * KSTEP, kc = kb - p.c0;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                fa[f] = poff[f] >= 0 ? ld128(src + poff[f] + kc) : zero;
+                fo[f] = qoff[f] >= 0 ? ld128(oth + qoff[f] + kc) : zero;
+            }
+            table(ks, scv, shv);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fw[b] = woff[b] >= 0 ? ld128(wg + woff[b] + kb) : zero;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) affine(fa[f], poff[f] >= 0, scv, shv, &fo[f]);
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) Mma<T>::run(acc[f][b], fw[u][b], fa[u][f]);
+                for (int b = 0; b < NB; ++b) Mma<T>::run(acc[f][b], fw[b], fa[f]);
         }
     }
     // partial d tile of this wave: pixel f*16 + l15, virtual channels b*16 + 4q .. +3
