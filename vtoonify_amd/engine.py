@@ -696,7 +696,9 @@ class VToonifyEngine:
                         # (vt_conv_desc.in_absdiff + in_scale / in_shift: bit-identical to vt_affine_apply -> conv, without
                         # the launch and the 2C-channel normalised copy).  VT_GATE_LOADER=0: the two launches (A/B)
                         gate_kw = dict(src0=out, c0=co, ld0=co, src1=f_e, c1=co, ld1=co, in_scale=sc, in_shift=sh, in_absdiff=1)
-                        in_loader = (not fus_plane and os.environ.get("VT_GATE_LOADER", "1") != "0" and
+                        # (not at the H/8 level: 16 tiles per frame cannot hide the one-step-in-flight second half of the
+                        # prologue form's K range -- 38 us against 7 + 18 for the two launches)
+                        in_loader = (not fus_plane and os.environ.get("VT_GATE_LOADER", "1") != "0" and hw >= 4096 and
                                      self._conv_kind(**gate_kw, **mask_kw) == 6)
                         if in_loader:
                             self._op_conv(ops, plan, **gate_kw, **mask_kw)
