@@ -446,6 +446,24 @@ def test_engine_housekeeping_round3(dev, monkeypatch):
     assert m.engine() is not e0
 
 
+def test_fusion_gate_in_the_loader_is_bit_identical(dev, monkeypatch):
+    """The Fusion gate's mask conv with cat[f_G, |f_G - f_E|] + AdaIN affine formed in its loader (vt_conv_desc.in_absdiff,
+    the default from the H/4 level up) against vt_affine_apply + plain conv: the same frames, bit for bit."""
+    sd = synth.synth_state_dict(load_keys("D"), 0)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    x = synth.synth_frames(2, 16, 24, seed=3).to(dev)
+    s = synth.synth_style(seed=17).to(dev)
+    for dtype in ((torch.bfloat16,) if dev.type != "cuda" else (torch.float32, torch.bfloat16)):   # (CPU emulation: one dtype)
+        outs = []
+        for mode in ("0", "2"):                      # never / at every level (the default skips the H/8 level)
+            monkeypatch.setenv("VT_GATE_LOADER", mode)
+            eng = VToonifyEngine(sdd, "dualstylegan", 256, dtype, dev)
+            outs.append(eng.forward(x, s.repeat(2, 1, 1), 0.5).clone())
+            n_aff = sum(1 for op in eng._plans[next(iter(eng._plans))].gen_ops if op[2].get("kernel") == "affine_apply")
+            assert n_aff == (4 if mode == "0" else 0)
+        assert torch.equal(outs[0], outs[1]), dtype
+
+
 def test_style_gate_is_transparent(dev):
     """VToonifyEngine(style_gate=True) (what the drop-in module uses): the style path is skipped ON THE DEVICE when a call's
     W+ rows and d_s equal the ones its products were computed from -- the video loop's `s_w.repeat(B,1,1)` is a new tensor

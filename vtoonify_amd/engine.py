@@ -698,7 +698,8 @@ class VToonifyEngine:
                         gate_kw = dict(src0=out, c0=co, ld0=co, src1=f_e, c1=co, ld1=co, in_scale=sc, in_shift=sh, in_absdiff=1)
                         # (not at the H/8 level: 16 tiles per frame cannot hide the one-step-in-flight second half of the
                         # prologue form's K range -- 38 us against 7 + 18 for the two launches)
-                        in_loader = (not fus_plane and os.environ.get("VT_GATE_LOADER", "1") != "0" and hw >= 4096 and
+                        gl = os.environ.get("VT_GATE_LOADER", "1")   # 0: never, 2: at every level (tests)
+                        in_loader = (not fus_plane and gl != "0" and (hw >= 4096 or gl == "2") and
                                      self._conv_kind(**gate_kw, **mask_kw) == 6)
                         if in_loader:
                             self._op_conv(ops, plan, **gate_kw, **mask_kw)
