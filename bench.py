@@ -426,15 +426,43 @@ def main():
 
     elapsed, blocks = timed_blocks(step, args.steps, dev, args.min_seconds)
 
+    # the headline's lane-0 plan, held from here on: the extras below build more plans than the engine's LRU keeps
+    # (ADVICE r3), and the per-kernel pass at the end must time THIS plan, not a rebuilt one
+    headline_plan = eng.plan_for(B, H, W, True, d_s != 0.0) if rank == 0 else None
+
+    # the same workload with ONE frame in flight (latency view; not `value`) -- measured before the extras, while the
+    # headline's plans and graphs are the ones in the cache (no rebuild / capture inside a timed repetition)
+    single = None
+    module_call = None
+    reps = 1 if emu else 5
+    if rank == 0 and (lanes > 1 or emu):
+        n1 = min(args.steps, 1 if emu else 50)
+        def s1(i):
+            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0, borrow=True)
+        s1(0)   # warm (a no-op when lane 0's plan is resident)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            for i in range(n1):
+                s1(i)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        t1 = sorted(ts)[len(ts) // 2]
+        single = {"value": n1 * B / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1e3 * t1 / n1,
+                  "steps_in_flight": 1, "frames_per_step": B, "blocks": len(ts)}
+
     def lanes_rate(bb, hh, ww, nsteps, engine=None, ds=None, n_lanes=None, note=None):
         """frames/s of another (batch, size, engine, style degree) on this rank's GPU, `lanes` steps in flight, all ranks."""
         e = engine or eng
         dd = d_s if ds is None else ds
         nl = n_lanes or lanes
+        while len(streams) < nl and not emu:   # `--lanes 1` with an extra that wants two steps in flight (ADVICE r3)
+            streams.append(torch.cuda.Stream(dev))
         pl = [synth.synth_frames(bb, hh, ww, seed=5000 + 1000 * rank + i).to(dev) for i in range(2)]
         def st(i):
             ln = i % nl
-            with torch.cuda.stream(streams[ln]):
+            with torch.cuda.stream(streams[ln] if ln < len(streams) else None):
                 return e.forward(pl[i % 2], style, dd, shared_style=True, use_graph=use_graph, lane=ln, borrow=True)
         for i in range(nl if emu else nl + 2):
             st(i)
@@ -483,6 +511,9 @@ def main():
             eng32 = VToonifyEngine(sd_dev, args.backbone, 256, torch.float32, dev)
             f32 = lanes_rate(1, H, W, 16, engine=eng32, note="fp32 end to end (v_mfma_f32_16x16x4_f32), the reference's precision")
             f32["single_stream"] = lanes_rate(1, H, W, 12, engine=eng32, n_lanes=1)["value"]
+            if B > 1:   # ... and at the headline's frames per step (missing 3)
+                f32["headline_batch"] = lanes_rate(B, H, W, 8, engine=eng32,
+                                                   note=f"fp32 end to end, {B} frames per step like `value`")
             rows32, roof32 = kernel_table(eng32, eng32.plan_for(1, H, W, True, d_s != 0.0), torch.float32, 2)
             f32["roofline"] = roof32
             f32["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows32[:4]]
@@ -502,25 +533,6 @@ def main():
         torch.cuda.empty_cache()
         extras["op_surface"] = op_surface(dev)
 
-    # the same workload with ONE frame in flight (latency view; not `value`)
-    single = None
-    module_call = None
-    reps = 1 if emu else 5
-    if rank == 0 and (lanes > 1 or emu):
-        n1 = min(args.steps, 1 if emu else 50)
-        def s1(i):
-            return eng.forward(pool[i % len(pool)], style, d_s, shared_style=True, use_graph=use_graph, lane=0, borrow=True)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(reps):
-            t1 = time.perf_counter()
-            for i in range(n1):
-                s1(i)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t1)
-        t1 = sorted(ts)[len(ts) // 2]
-        single = {"value": n1 * B / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1e3 * t1 / n1,
-                  "steps_in_flight": 1, "frames_per_step": B, "blocks": len(ts)}
     if rank == 0 and not args.no_extras:
         # through the drop-in module: VToonify(...).load_state_dict(...); model(x, s_w.repeat(B,1,1), d_s=...)
         # exactly as style_transfer.py:62-64,176 calls it (hipGraph replay by default, one frame in flight)
@@ -569,7 +581,7 @@ def main():
     if rank == 0:
         fps = ws * args.steps * B / elapsed
         # ---- per-kernel timing (HIP events on the launch stream), dominant kernel ----------
-        plan = eng.plan_for(B, H, W, True, d_s != 0.0)
+        plan = headline_plan
         rows, roofline, per_op = kernel_table(eng, plan, dtype, max(1, args.op_iters), emu=emu, want_ops=True)
         if args.kernels:
             for r in rows:

@@ -576,6 +576,48 @@ def test_conv_batch_aware_tiles(dev, monkeypatch):
             monkeypatch.delenv("VT_BATCH_EXACT")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
+    """conv_patchp_kernel (csrc/conv_patch_pipe.hpp: fragments of tap s+1 read before the barrier of tap s, 4-deep weight
+    ring, one patch piece per tap, LDS-DMA between the two halves of a tap) sums K in the order of conv_patch_kernel
+    ([chunk][tap][half]): the 256-pixel tiles must give the SAME BITS on both -- several chunks (the double-buffered
+    patch), two concatenated sources, ragged tile edges, a batch, split-K slices, residual + activation epilogue."""
+    unit = 64 if dtype == torch.bfloat16 else 32
+    g = np.random.default_rng(31)
+    for N, c0, c1, H, W, cout, hint in ((2, 3 * unit, 0, 21, 35, 136, P + 256128),
+                                        (1, unit, 2 * unit, 17, 16, 128, P + 256128),
+                                        (1, 2 * unit, 0, 16, 33, 72, P + 256064),
+                                        (1, 4 * unit, 0, 19, 18, 136, P + 2000000 + 256128)):
+        cin = c0 + c1
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xa = K.nchw_to_nhwc(T(x[:, :c0], dev), dtype)
+        xb = K.nchw_to_nhwc(T(x[:, c0:], dev), dtype) if c1 else None
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        ldo = (cout + 7) // 8 * 8
+        r = K.nchw_to_nhwc(T(g.standard_normal((N, cout, H, W)).astype(np.float32), dev), dtype, ld_out=ldo)
+        ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+
+        def run():
+            out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
+            kw = dict(src1=xb, c1=c1, ld1=c1) if c1 else {}
+            K.conv2d(src0=xa, c0=c0, ld0=c0, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, alpha=0.5, beta=0.25, resid=r, ld_res=ldo, out=out,
+                     ld_out=ldo, dtype=K.dt_code(dtype), tile_hint=hint, splitk_ws=ws, **kw)
+            return out
+        monkeypatch.setenv("VT_PATCH_PIPE", "0")
+        ref = run()
+        monkeypatch.delenv("VT_PATCH_PIPE")
+        got = run()
+        assert torch.equal(got, ref), (N, c0, c1, H, W, cout, hint)
+        xq = torch.cat([xa] + ([xb] if c1 else []), dim=3).float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        want = O.leaky_relu(O.conv2d(xq, wq, b, 1, 1, 1), 0.2) * np.float32(2 ** 0.5) * 0.5 + \
+            0.25 * r.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy()
+        assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < (F32_TOL if dtype == torch.float32 else 8e-3)
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--adain", type=int, default=0,
                     help="whole-K trunk convs: bit 0 = AdaIN consumer (in_tile_stats + in_gb), bit 1 = emit tile_stats, bit 2 = residual")
     ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
+    ap.add_argument("--sweep", default="", help="VAR=a,b,c: time every shape under each value of an environment switch the "
+                    "library reads per call (same process, same buffers: a same-box A/B)")
     args = ap.parse_args()
     _lib.use_library(_lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
@@ -147,21 +149,26 @@ def main():
             print(f"{name:<28} rejected: {lib.vt_last_error().decode()}")
             continue
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for _ in range(3):
-            _lib.check(lib.vt_conv2d(C.byref(d), st), "conv")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            lib.vt_conv2d(C.byref(d), st)
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / args.iters
-        m = n * ho * wo
-        flops = 2.0 * m * (4 if upb else phases) * cout * k * k * cin   # MACs of the polyphase form, for comparison
-        nbytes = x.numel() * esz + wt.numel() * esz + out.numel() * out.element_size()
-        tot += us
-        print(f"{name:<28} tile {tile:>9d} M={m:8d} N={phases * cout:5d} K={k * k * cin:5d} {us:9.1f} us "
-              f"{flops / us / 1e6:8.1f} TF/s {nbytes / us / 1e3:8.1f} GB/s")
+        var, vals = (args.sweep.split("=")[0], args.sweep.split("=")[1].split(",")) if args.sweep else ("", [""])
+        for val in vals * (2 if args.sweep else 1):   # a sweep runs twice round: drift shows as a difference between rounds
+            if var:
+                os.environ[var] = val
+            for _ in range(3):
+                _lib.check(lib.vt_conv2d(C.byref(d), st), "conv")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                lib.vt_conv2d(C.byref(d), st)
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.iters
+            m = n * ho * wo
+            flops = 2.0 * m * (4 if upb else phases) * cout * k * k * cin   # MACs of the polyphase form, for comparison
+            nbytes = x.numel() * esz + wt.numel() * esz + out.numel() * out.element_size()
+            tot += us
+            tag = f" {var}={val}" if var else ""
+            print(f"{name:<28} tile {tile:>9d} M={m:8d} N={phases * cout:5d} K={k * k * cin:5d} {us:9.1f} us "
+                  f"{flops / us / 1e6:8.1f} TF/s {nbytes / us / 1e3:8.1f} GB/s{tag}")
     print(f"total {tot:.1f} us")
 
 

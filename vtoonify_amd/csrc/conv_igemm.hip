@@ -28,6 +28,7 @@
 // pixel-shuffle for the polyphase up-sampling conv, NHWC or planar NCHW stores) runs
 // from an LDS-staged fp32 tile so every global store is a full 16-byte vector.
 #include <stdlib.h>
+#include <utility>
 
 #include "vt_common.hpp"
 
@@ -1371,6 +1372,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #include "conv_upblur.hpp"
 #include "conv_thin.hpp"
 #include "conv_c64.hpp"
+#include "conv_patch_pipe.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -2022,6 +2024,31 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
+template <typename T, int TH, int BN, int WM, int WN, int PIN = 1>
+int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    ConvArgs args = a;
+    args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;   // matches PERM of the kernel instance
+    args.tiles_n = vt_cdiv(a.coutT, BN);
+    args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
+    const int units = a.cin / BK;
+    args.kps = vt_cdiv(units, args.splitk);
+    args.splitk = vt_cdiv(units, args.kps);
+    split_mode(args);
+    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n * args.splitk;
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    if (args.phase != 2) {
+        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, PIN>;
+        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+    }
+    int rc = vt_check_launch("vt_conv2d(patch, pipelined)");
+    if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
+    return launch_reduce<T>(args, stream);
+}
+
 template <typename T>
 int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     ConvArgs args = a;
@@ -2173,6 +2200,18 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
 #define VT_PATCH(TH_, BN_, WM_, WN_, DIL_, NSTB_, ABUF_, COND_) \
     if (t.bm == TH_ * 16 && t.bn == BN_ && a.dil == DIL_ && (COND_))  \
         return launch_patch<T, TH_, BN_, WM_, WN_, DIL_, NSTB_, ABUF_>(a, g, stream);
+        {
+            // software-pipelined form of the 256-pixel tiles (conv_patch_pipe.hpp; same K order, same bits).
+            // VT_PATCH_PIPE=0: the per-tap form below (A/B; read per call: tests flip it)
+            const char* e = getenv("VT_PATCH_PIPE");
+            const bool pipe = !(e && e[0] == '0');
+            if constexpr (sizeof(T) == 2) {   // A/B of the pinned interleave (tools/conv_bench.py; removed once measured)
+                if (pipe && e && e[0] == '2' && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2, 0>(a, g, stream);
+                if (pipe && e && e[0] == '3' && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2, 2>(a, g, stream);
+            }
+            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
+            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2>(a, g, stream);
+        }
         VT_PATCH(16, 128, 4, 2, 1, 3, 2, true)
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)
         VT_PATCH(8, 64, 2, 2, 1, 3, 2, true)

@@ -1,0 +1,230 @@
+// Patch-resident 3x3 convolution, software-pipelined across the per-tap barrier (round 4).
+// Included by conv_igemm.hip inside its anonymous namespace (uses ConvArgs, GldsArgs, Mma, conv_epilogue, PatchRows).
+//
+// conv_patch_kernel (conv_igemm.hip) runs every filter tap as: barrier -> issue LDS-DMA -> read the first fragments ->
+// s_waitcnt lgkmcnt(0) -> MFMAs, so the matrix pipe of every SIMD idles for one LDS round trip (with all 8 waves
+// of the workgroup queueing on the LDS at once) plus the LDS-DMA issue cost at the top of each of the 9 x chunks
+// taps: measured MFMA-busy 0.36 on the 256 x 128 tiles (profiles/r03_pmc_mfma.json).  This form keeps the same tile,
+// the same loader and the same K order ([chunk][tap][half], so the results are bit-identical) and removes that
+// bubble:
+//   * the weight ring is 4 deep and the barrier at the end of tap s publishes the weights of tap s+2, so tap s+1's
+//     fragments may be read BEFORE the barrier that ends tap s;
+//   * fragments are double-buffered in registers: while the 16 MFMAs of one half-step run, the 8 ds_read_b128 of the
+//     next half-step (the first half of the NEXT tap in the second half of a tap) are in flight -- the interleave is
+//     pinned with sched_group_barrier, one read per MFMA;
+//   * the LDS-DMA for tap s+3 is issued between the two halves, not at the top of the step, and the next chunk's patch
+//     arrives one 1 KB piece per wave per tap (taps 0..PA-1) instead of PA pieces at once;
+//   * the 9 taps are unrolled at compile time: every LDS offset of a fragment read is an immediate, every counted
+//     `s_waitcnt vmcnt` is a constant (no branch ladder in front of the barrier), and loads past the end of the K
+//     range are issued with an out-of-range offset (the buffer unit zero-fills a dead slot) so that every wave
+//     issues the same number of operations in every step.
+// LDS: 2 patch buffers + 4 weight slots = all 160 KB for the 256-pixel x 128-channel tile (one workgroup per CU).
+#pragma once
+
+template <int... I, typename F>
+__device__ __forceinline__ void vt_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void vt_static_for(F&& f) {
+    vt_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int PIN = 1>
+__global__ void __launch_bounds__(WM * WN * 64)
+conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
+    constexpr int TW = 16;
+    constexpr int NW = WM * WN;                 // wavefronts
+    constexpr int BM = TH * TW;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VEC = 16 / ESZ;
+    constexpr int BK = 8 * VEC;                 // channels per chunk (128 B)
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr bool PERM = (TN % 2 == 0);        // weight rows in fragment order: see tile_row_channel
+    constexpr int PH = TH + 2, PW = TW + 2, PROWS = PH * PW;
+    constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch pieces (1 KB loads) per wave per chunk
+    constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
+    constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
+    constexpr int NSTB = 4;
+    static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiling");
+    static_assert(TM * WM == TH, "one 16-pixel tile row per MFMA row block");
+    static_assert((TM * PW) % 8 == 0, "the swizzle phase of a fragment row must not depend on the wave");
+    static_assert(PA <= 6, "the last patch piece (tap PA-1) must have landed two taps before tap 8 reads the next chunk");
+    static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (NW - 1);
+    const int wm = wave / WN, wn = wave % WN;
+    int tile_m, tile_n, split;
+    decode_block(p, tile_m, tile_n, split);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int n0 = tile_n * BN;
+
+    // ---- loader state (fixed for the whole kernel: only the SGPR offset moves) -------------
+    const int lrow = lane >> 3;
+    const int jj = (lane & 7) ^ lrow;
+    uint32_t pa0[PA], pa1[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pr = (i * NW + wave) * 8 + lrow;
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
+        pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
+        pa1[i] = in ? pix * (uint32_t)(p.ld1 * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    uint32_t woff[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int n = n0 + tile_row_channel<PERM>(row);
+        woff[i] = (row < BN && n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
+    }
+    const BufRsrc r0 = vt_make_rsrc(p.src0, g.nrec0);
+    const BufRsrc r1 = vt_make_rsrc(p.src1 ? p.src1 : p.src0, p.src1 ? g.nrec1 : 0u);
+    const BufRsrc rw = vt_make_rsrc(p.wgt, g.nrecw);
+
+    // K slices are whole chunks: p.kps chunks per slice
+    const int nchunks = p.cin / BK;
+    const int ch0 = split * p.kps;
+    const int ch1 = (ch0 + p.kps < nchunks) ? ch0 + p.kps : nchunks;
+
+    // piece `i` of the patch of `chunk` -> patch buffer at byte offset `aoff`; chunks at or beyond ch1 fetch zeros
+    auto issue_a_piece = [&](int chunk, int aoff, int i) {
+        const bool live = chunk < ch1;
+        const int kc = chunk * BK;
+        const bool s1 = live && kc >= p.c0;
+        const uint32_t so = live ? (uint32_t)((s1 ? kc - p.c0 : kc) * ESZ) : 0u;
+        const uint32_t vo = live ? (s1 ? pa1[i] : pa0[i]) : GLDS_OOB;
+        vt_glds16(s1 ? r1 : r0, smem + aoff + (i * NW + wave) * 1024, vo, so);
+    };
+    // weights of (chunk, tap) -> ring slot at byte offset `boff`
+    auto issue_b = [&](int chunk, int tap, int boff) {
+        const bool live = chunk < ch1;
+        const uint32_t so = live ? (uint32_t)((tap * p.cin + chunk * BK) * ESZ) : 0u;
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            vt_glds16(rw, smem + 2 * A_BYTES + boff + (i * NW + wave) * 1024, live ? woff[i] : GLDS_OOB, so);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
+    // per-lane parts of the fragment addresses.  A: patch row pr = rowconst + wm*TM*PW + l15 with rowconst a compile-time
+    // function of (tap, a); its swizzle phase is (pr & 7) = (l15 + (rowconst & 7)) & 7 -> one of 8 lane patterns per half
+    uint32_t aswz[8][2];
+#pragma unroll
+    for (int cm = 0; cm < 8; ++cm)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+            aswz[cm][sub] = (uint32_t)((wm * TM * PW + l15) * 128 + (((sub * 4 + q) ^ ((l15 + cm) & 7)) << 4));
+    uint32_t bfix[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+        bfix[sub] = (uint32_t)(2 * A_BYTES + (wn * (TN * 16) + l15) * 128 + (((sub * 4 + q) ^ l7) << 4));
+
+    u128 fa[2][TM], fb[2][TN];
+    // fragments of (tap TAP, half SUB) from the patch at `aoff` and the weight slot at `boff`, in the order the MFMAs
+    // consume them: fa[0], fb[0..TN-1], fa[1..TM-1]
+    auto read_frags = [&](auto tapc, auto subc, u128 (&xa)[TM], u128 (&xb)[TN], int aoff, int boff) {
+        constexpr int TAP = decltype(tapc)::value, SUB = decltype(subc)::value;
+        constexpr int ky = TAP / 3, kx = TAP - ky * 3;
+        auto ra = [&](int a) {
+            const int rowc = (a + ky) * PW + kx;   // folds: a and TAP are compile-time after unrolling
+            xa[a] = ld128(smem + aoff + aswz[rowc & 7][SUB] + rowc * 128);
+        };
+        ra(0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) xb[b] = ld128(smem + boff + bfix[SUB] + b * 2048);
+#pragma unroll
+        for (int a = 1; a < TM; ++a) ra(a);
+    };
+    auto mma_all = [&](const u128 (&xa)[TM], const u128 (&xb)[TN]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], xb[b], xa[a]);
+    };
+    // pinned interleave of one half-step: one fragment read of the next half-step per MFMA (per 4 fp32 MFMAs), then
+    // the remaining MFMAs
+    constexpr int MPF = (ESZ == 4) ? 4 : 1;       // machine MFMAs per fragment product
+    // PIN (A/B, tools/conv_bench.py): 0 = hipcc's own order, 1 = one read per MFMA then the rest, 2 = one read per two MFMAs
+    auto pin_half = [&]() {
+        if constexpr (PIN == 1) {
+            vt_static_for<TM + TN>([&](auto) {
+                vt_sched_group<0x100, 1>();
+                vt_sched_group<0x008, MPF>();
+            });
+            if constexpr (TM * TN > TM + TN) vt_sched_group<0x008, (TM * TN - TM - TN) * MPF>();
+        } else if constexpr (PIN == 2) {
+            constexpr int PER = (TM * TN) / (TM + TN) > 0 ? (TM * TN) / (TM + TN) : 1;
+            vt_static_for<TM + TN>([&](auto) {
+                vt_sched_group<0x100, 1>();
+                vt_sched_group<0x008, PER * MPF>();
+            });
+            if constexpr (TM * TN > PER * (TM + TN)) vt_sched_group<0x008, (TM * TN - PER * (TM + TN)) * MPF>();
+        }
+    };
+
+    // ---- prologue: patch of the first chunk, weights of taps 0..2; patch + taps 0, 1 landed -------------
+#pragma unroll
+    for (int i = 0; i < PA; ++i) issue_a_piece(ch0, 0, i);
+    issue_b(ch0, 0, 0 * B_BYTES);
+    issue_b(ch0, 1, 1 * B_BYTES);
+    issue_b(ch0, 2, 2 * B_BYTES);
+    vt_glds_wait_n<LB>();
+    vt_lds_barrier();
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa[0], fb[0], 0, 0);
+
+    int aoff = 0;        // patch buffer of the current chunk
+    int slot = 0;        // ring slot of the current tap (step & 3)
+    for (int chunk = ch0; chunk < ch1; ++chunk) {
+        vt_static_for<9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int t3 = (t + 3) % 9, c3 = (t + 3) / 9;       // (chunk + c3, tap t3) is issued in this step
+            constexpr int t1 = (t + 1) % 9;
+            const int boff = slot * B_BYTES;
+            const int boff1 = ((slot + 1) & 3) * B_BYTES, boff3 = ((slot + 3) & 3) * B_BYTES;
+            vt_sched_fence();
+            // first half: MFMAs on the fragments read before the barrier; the second half's fragments arrive
+            read_frags(tc, std::integral_constant<int, 1>{}, fa[1], fb[1], aoff, boff);
+            mma_all(fa[0], fb[0]);
+            pin_half();
+            // LDS-DMA of this step: weights of tap s+3 into the slot tap s-1 used (every wave is past it: barrier of
+            // step s-1), one piece of the next chunk's patch into the other patch buffer
+            issue_b(chunk + c3, t3, boff3);
+            if constexpr (t < PA) issue_a_piece(chunk + 1, aoff ^ A_BYTES, t);
+            if constexpr (PIN != 0) vt_sched_group<0x020, LB + (t < PA ? 1 : 0)>();
+            // second half: MFMAs on the second half's fragments; the first half of tap s+1 arrives (its weights were
+            // published by the barrier of step s-1, its patch -- at t == 8 the next chunk's -- by that of tap 7)
+            read_frags(std::integral_constant<int, t1>{}, std::integral_constant<int, 0>{}, fa[0], fb[0],
+                       t == 8 ? (aoff ^ A_BYTES) : aoff, boff1);
+            mma_all(fa[1], fb[1]);
+            pin_half();
+            vt_sched_fence();
+            // the weights of tap s+2 (issued in step s-1) must have landed: younger are the patch piece of step s-1, this
+            // step's weights and this step's patch piece
+            vt_glds_wait_n<LB + (t < PA ? 1 : 0) + ((t >= 1 && t - 1 < PA) ? 1 : 0)>();
+#ifdef VT_EMU
+            vt_lds_barrier();
+#else
+            __builtin_amdgcn_s_barrier();   // fragment reads in flight cross it: they read slots this barrier does not free
+#endif
+            slot = (slot + 1) & 3;
+        });
+        aoff ^= A_BYTES;
+    }
+    __syncthreads();
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split, tile_n * p.tiles_m + tile_m);
+}
