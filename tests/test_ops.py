@@ -543,7 +543,9 @@ def test_conv_batch_aware_tiles(dev, monkeypatch):
     assert code(1, 512, 64, 64, 512, stream=True) // 100000000 in (4, 8)   # whole-K kernels for one frame ...
     assert code(4, 512, 64, 64, 512, stream=True) == 101256128             # ... patch tiles for a batch that fills the GPU
     assert code(4, 512, 64, 64, 512, stream=True, exact="1") // 100000000 in (4, 8)
-    assert code(4, 512, 32, 32, 512, stream=True) // 100000000 == 8    # the 32 x 32 trunk stays weight-stationary
+    assert code(4, 512, 32, 32, 512, stream=True) == 101256032         # the 32 x 32 trunk: 32-channel tiles, one per CU
+    assert code(2, 512, 32, 32, 512, stream=True) // 100000000 == 8    # ... two frames do not fill the GPU: weight-stationary
+    assert code(4, 512, 32, 32, 512, stream=True, exact="1") // 100000000 == 8
     monkeypatch.delenv("VT_BATCH_EXACT", raising=False)
     if dev.type != "cuda":
         return
@@ -584,10 +586,14 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
     patch), two concatenated sources, ragged tile edges, a batch, split-K slices, residual + activation epilogue."""
     unit = 64 if dtype == torch.bfloat16 else 32
     g = np.random.default_rng(31)
-    for N, c0, c1, H, W, cout, hint in ((2, 3 * unit, 0, 21, 35, 136, P + 256128),
-                                        (1, unit, 2 * unit, 17, 16, 128, P + 256128),
-                                        (1, 2 * unit, 0, 16, 33, 72, P + 256064),
-                                        (1, 4 * unit, 0, 19, 18, 136, P + 2000000 + 256128)):
+    # (the 32-channel tiles -- deep weight ring, three patch pieces per tap -- have no per-tap twin: the K order does not
+    # depend on the tile width, so their reference is the 128-channel per-tap instance)
+    for N, c0, c1, H, W, cout, hint, ref_hint in ((2, 3 * unit, 0, 21, 35, 136, P + 256128, P + 256128),
+                                                  (1, unit, 2 * unit, 17, 16, 128, P + 256128, P + 256128),
+                                                  (1, 2 * unit, 0, 16, 33, 72, P + 256064, P + 256064),
+                                                  (1, 4 * unit, 0, 19, 18, 136, P + 2000000 + 256128, P + 2000000 + 256128),
+                                                  (2, 3 * unit, 0, 21, 35, 136, P + 256032, P + 256128),
+                                                  (1, unit, 2 * unit, 33, 17, 40, P + 256032, P + 256128)):
         cin = c0 + c1
         x = g.standard_normal((N, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
@@ -599,7 +605,7 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
         r = K.nchw_to_nhwc(T(g.standard_normal((N, cout, H, W)).astype(np.float32), dev), dtype, ld_out=ldo)
         ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
 
-        def run():
+        def run(hint):
             out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
             kw = dict(src1=xb, c1=c1, ld1=c1) if c1 else {}
             K.conv2d(src0=xa, c0=c0, ld0=c0, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
@@ -607,9 +613,9 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
                      ld_out=ldo, dtype=K.dt_code(dtype), tile_hint=hint, splitk_ws=ws, **kw)
             return out
         monkeypatch.setenv("VT_PATCH_PIPE", "0")
-        ref = run()
+        ref = run(ref_hint)
         monkeypatch.delenv("VT_PATCH_PIPE")
-        got = run()
+        got = run(hint)
         assert torch.equal(got, ref), (N, c0, c1, H, W, cout, hint)
         xq = torch.cat([xa] + ([xb] if c1 else []), dim=3).float().cpu().permute(0, 3, 1, 2).numpy()
         wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)

@@ -83,7 +83,7 @@ case $name in
     $CB --only "rgb " --batch 4 --iters 30 2>/dev/null | grep '^rgb' ;;
   pipe)   # round 4: software-pipelined 256-pixel patch tiles (VT_PATCH_PIPE: 0 per-tap form, 1 pinned 1:1, 2 unpinned, 3 pinned 1:2)
     for only in "=same 256 @128" "=fus2 512->256 @128" "=enc2.2 512->512 @64" "=fus1 1024->512 @64" "=same 128 @256"; do
-      $CB --stream --only "$only" --batch 4 --iters 30 --sweep VT_PATCH_PIPE=0,1,2,3 2>/dev/null | grep -v '^total\|amdgpu'
+      $CB --stream --only "$only" --batch 4 --iters 30 --sweep ${PIPE_SWEEP:-VT_PATCH_PIPE=0,1,2,3} 2>/dev/null | grep -v '^total\|amdgpu'
     done
     $CB --dtype fp32 --stream --only "=same 256 @128" --batch 4 --iters 10 --sweep VT_PATCH_PIPE=0,1 2>/dev/null | grep -v '^total\|amdgpu' ;;
   *) echo "unknown experiment $name"; exit 1 ;;

@@ -1867,6 +1867,21 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
                 t.splitk = 1;
                 return t;
             }
+            // Round 4: the same for the 32 x 32 trunk, where 256 x 128 tiles would leave three CUs in four idle: 256-pixel x
+            // 32-channel tiles of the pipelined patch kernel (conv_patch_pipe.hpp; one workgroup per CU at 4 frames, weights
+            // 8 taps ahead).  A workgroup then ingests 77 KB per 64-channel chunk -- the 41 KB patch once, not the 61 KB per
+            // 32-pixel step of the weight-stationary kernel: 28.7 -> 24.5 us per conv before tuning, 66 -> 44 us for the
+            // 1024 -> 512 fusion conv (profiles/r04_patch_pipeline.txt).  bf16 only (fp32 is MFMA-bound either way and keeps
+            // the per-image plans of the parity mode); same rule as above for VT_BATCH_EXACT.
+            const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && a.dil == 1 &&
+                                       a.coutT >= 128 && !a.tile_stats && !a.in_tile_stats && !a.stats_part &&
+                                       (int64_t)a.N * ptiles(16, 32) >= 256 && !batch_exact() && patch_eligible<T>(a, g);
+            if (batch_patch32) {
+                t.kind = 1;
+                t.bm = 256, t.bn = 32;
+                t.splitk = 1;
+                return t;
+            }
             if (hinted || fk_mode >= 2 || (a.coutT >= 128 && wgs <= fk_max_wgs)) {
                 t.kind = 4;
                 t.bm = FK_TH * FK_TW;
@@ -2024,7 +2039,7 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int PIN = 1>
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int PIN = 0, int ABL = 0>
 int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
@@ -2041,7 +2056,7 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         return VT_ERR_ARG;
     }
     if (args.phase != 2) {
-        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, PIN>;
+        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, PIN, ABL>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
     }
     int rc = vt_check_launch("vt_conv2d(patch, pipelined)");
@@ -2205,12 +2220,23 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // VT_PATCH_PIPE=0: the per-tap form below (A/B; read per call: tests flip it)
             const char* e = getenv("VT_PATCH_PIPE");
             const bool pipe = !(e && e[0] == '0');
-            if constexpr (sizeof(T) == 2) {   // A/B of the pinned interleave (tools/conv_bench.py; removed once measured)
-                if (pipe && e && e[0] == '2' && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2, 0>(a, g, stream);
-                if (pipe && e && e[0] == '3' && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2, 2>(a, g, stream);
+            if constexpr (sizeof(T) == 2) {   // A/B + ablations (tools/conv_bench.py; removed once measured)
+                const bool big = pipe && e && a.dil == 1 && t.bm == 256 && t.bn == 128;
+                if (big && e[0] == '2') return launch_patchp<T, 16, 128, 4, 2, 4, 1>(a, g, stream);
+                if (big && e[0] == '3') return launch_patchp<T, 16, 128, 4, 2, 4, 2>(a, g, stream);
+                if (big && e[0] == '4') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 4>(a, g, stream);
+                if (big && e[0] == '5') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 5>(a, g, stream);
+                if (big && e[0] == '6') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 6>(a, g, stream);
+                if (big && e[0] == '9') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 7>(a, g, stream);
+                if (big && e[0] == 'a') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 8>(a, g, stream);
             }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2>(a, g, stream);
+            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) {
+                if (e && e[0] == '7') return launch_patchp<T, 16, 32, 8, 1, 4>(a, g, stream);
+                if (e && e[0] == '8') return launch_patchp<T, 16, 32, 8, 1, 6>(a, g, stream);
+                return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
+            }
         }
         VT_PATCH(16, 128, 4, 2, 1, 3, 2, true)
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)

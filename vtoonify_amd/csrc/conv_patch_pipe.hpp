@@ -30,7 +30,7 @@ __device__ __forceinline__ void vt_static_for(F&& f) {
     vt_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int PIN = 1>
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int PIN = 0, int ABL = 0>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int TW = 16;
@@ -45,12 +45,18 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch pieces (1 KB loads) per wave per chunk
     constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
     constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
-    constexpr int NSTB = 4;
+    // NSTB = weight ring depth: the weights of tap s+D (D = NSTB-1) are issued in tap s.  The barrier that ends tap s
+    // publishes tap s+2 whatever the depth; a deeper ring only lets the loads fly longer (the 32-channel tiles: 4 KB per
+    // tap, steps too short to cover an L2 round trip with two taps in flight).  A patch piece issued in tap t is older
+    // than the weights of tap t+D+1, which are waited for at the end of tap t+D-1: pieces go out in taps 0..8-D, PPT each.
+    constexpr int D = NSTB - 1;
+    constexpr int PTAPS = 9 - D;                            // taps that may carry patch pieces
+    constexpr int PPT = (PA + PTAPS - 1) / PTAPS;           // pieces per such tap
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiling");
     static_assert(TM * WM == TH, "one 16-pixel tile row per MFMA row block");
-    static_assert((TM * PW) % 8 == 0, "the swizzle phase of a fragment row must not depend on the wave");
-    static_assert(PA <= 6, "the last patch piece (tap PA-1) must have landed two taps before tap 8 reads the next chunk");
+    static_assert(NSTB >= 4 && NSTB <= 9, "ring depth");
     static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((D - 2) * LB + PA < 64, "vmcnt is 6 bits");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
 
@@ -122,19 +128,25 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
 
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     // per-lane parts of the fragment addresses.  A: patch row pr = rowconst + wm*TM*PW + l15 with rowconst a compile-time
-    // function of (tap, a); its swizzle phase is (pr & 7) = (l15 + (rowconst & 7)) & 7 -> one of 8 lane patterns per half
+    // function of (tap, a); its swizzle phase is (pr & 7) = (wm*TM*PW + l15 + (rowconst & 7)) & 7 -> one of 8 lane patterns per half
     uint32_t aswz[8][2];
 #pragma unroll
     for (int cm = 0; cm < 8; ++cm)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
-            aswz[cm][sub] = (uint32_t)((wm * TM * PW + l15) * 128 + (((sub * 4 + q) ^ ((l15 + cm) & 7)) << 4));
+            aswz[cm][sub] = (uint32_t)((wm * TM * PW + l15) * 128 + (((sub * 4 + q) ^ ((wm * TM * PW + l15 + cm) & 7)) << 4));
     uint32_t bfix[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
         bfix[sub] = (uint32_t)(2 * A_BYTES + (wn * (TN * 16) + l15) * 128 + (((sub * 4 + q) ^ l7) << 4));
 
     u128 fa[2][TM], fb[2][TN];
+    if constexpr (ABL == 7 || ABL == 8) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[1][a] = u128{1u, 2u, 3u, (uint32_t)lane};
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[1][b] = u128{4u, 5u, 6u, (uint32_t)lane};
+    }
     // fragments of (tap TAP, half SUB) from the patch at `aoff` and the weight slot at `boff`, in the order the MFMAs
     // consume them: fa[0], fb[0..TN-1], fa[1..TM-1]
     auto read_frags = [&](auto tapc, auto subc, u128 (&xa)[TM], u128 (&xb)[TN], int aoff, int boff) {
@@ -180,10 +192,11 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     // ---- prologue: patch of the first chunk, weights of taps 0..2; patch + taps 0, 1 landed -------------
 #pragma unroll
     for (int i = 0; i < PA; ++i) issue_a_piece(ch0, 0, i);
-    issue_b(ch0, 0, 0 * B_BYTES);
-    issue_b(ch0, 1, 1 * B_BYTES);
-    issue_b(ch0, 2, 2 * B_BYTES);
-    vt_glds_wait_n<LB>();
+    vt_static_for<D>([&](auto sc) {   // (D <= 8 taps: all of the first chunk)
+        constexpr int s0 = decltype(sc)::value;
+        issue_b(ch0, s0, s0 * B_BYTES);
+    });
+    vt_glds_wait_n<(D - 2) * LB>();
     vt_lds_barrier();
     read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa[0], fb[0], 0, 0);
 
@@ -192,36 +205,46 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     for (int chunk = ch0; chunk < ch1; ++chunk) {
         vt_static_for<9>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            constexpr int t3 = (t + 3) % 9, c3 = (t + 3) / 9;       // (chunk + c3, tap t3) is issued in this step
+            constexpr int t3 = (t + D) % 9, c3 = (t + D) / 9;       // (chunk + c3, tap t3) is issued in this step
             constexpr int t1 = (t + 1) % 9;
+            // patch pieces of this tap: [P0, P1); pieces younger than the weights of tap s+2 (issued in tap s+2-D): those of
+            // taps t-(D-2) .. t of this chunk (earlier taps of the previous chunk carry none: they are >= PTAPS)
+            constexpr int P0 = t * PPT < PA ? t * PPT : PA, P1 = (t + 1) * PPT < PA ? (t + 1) * PPT : PA;
+            constexpr int TLO = t - (D - 2) > 0 ? t - (D - 2) : 0;
+            constexpr int YOUNG = (P1 < PA ? P1 : PA) - (TLO * PPT < PA ? TLO * PPT : PA);
+            static_assert(t >= PTAPS ? P0 == P1 : true, "patch pieces only in the first 9-D taps");
             const int boff = slot * B_BYTES;
-            const int boff1 = ((slot + 1) & 3) * B_BYTES, boff3 = ((slot + 3) & 3) * B_BYTES;
+            const int slot1 = slot + 1 == NSTB ? 0 : slot + 1, slotd = slot == 0 ? NSTB - 1 : slot - 1;
+            const int boff1 = slot1 * B_BYTES, boff3 = slotd * B_BYTES;
             vt_sched_fence();
             // first half: MFMAs on the fragments read before the barrier; the second half's fragments arrive
-            read_frags(tc, std::integral_constant<int, 1>{}, fa[1], fb[1], aoff, boff);
+            if constexpr (ABL != 7 && ABL != 8) read_frags(tc, std::integral_constant<int, 1>{}, fa[1], fb[1], aoff, boff);
             mma_all(fa[0], fb[0]);
             pin_half();
             // LDS-DMA of this step: weights of tap s+3 into the slot tap s-1 used (every wave is past it: barrier of
             // step s-1), one piece of the next chunk's patch into the other patch buffer
-            issue_b(chunk + c3, t3, boff3);
-            if constexpr (t < PA) issue_a_piece(chunk + 1, aoff ^ A_BYTES, t);
-            if constexpr (PIN != 0) vt_sched_group<0x020, LB + (t < PA ? 1 : 0)>();
+            if constexpr (ABL != 4 && ABL != 8) {   // ABL (tools/conv_bench.py only, wrong results): 4 no LDS-DMA in the loop, 5 no barrier, 6 no vmcnt wait, 7 no fragment reads, 8 = 4 + 7
+                issue_b(chunk + c3, t3, boff3);
+                vt_static_for<P1 - P0>([&](auto ic) { issue_a_piece(chunk + 1, aoff ^ A_BYTES, P0 + decltype(ic)::value); });
+                if constexpr (PIN != 0) vt_sched_group<0x020, LB + P1 - P0>();
+            }
             // second half: MFMAs on the second half's fragments; the first half of tap s+1 arrives (its weights were
             // published by the barrier of step s-1, its patch -- at t == 8 the next chunk's -- by that of tap 7)
-            read_frags(std::integral_constant<int, t1>{}, std::integral_constant<int, 0>{}, fa[0], fb[0],
-                       t == 8 ? (aoff ^ A_BYTES) : aoff, boff1);
+            if constexpr (ABL != 7 && ABL != 8)
+                read_frags(std::integral_constant<int, t1>{}, std::integral_constant<int, 0>{}, fa[0], fb[0],
+                           t == 8 ? (aoff ^ A_BYTES) : aoff, boff1);
             mma_all(fa[1], fb[1]);
             pin_half();
             vt_sched_fence();
-            // the weights of tap s+2 (issued in step s-1) must have landed: younger are the patch piece of step s-1, this
-            // step's weights and this step's patch piece
-            vt_glds_wait_n<LB + (t < PA ? 1 : 0) + ((t >= 1 && t - 1 < PA) ? 1 : 0)>();
+            // the weights of tap s+2 (issued in step s+2-D) must have landed: younger are the weights of taps s+3 .. s+D and the
+            // patch pieces of the steps since (YOUNG)
+            if constexpr (ABL != 4 && ABL != 6 && ABL != 8) vt_glds_wait_n<(D - 2) * LB + YOUNG>();
 #ifdef VT_EMU
             vt_lds_barrier();
 #else
-            __builtin_amdgcn_s_barrier();   // fragment reads in flight cross it: they read slots this barrier does not free
+            if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();   // fragment reads in flight cross it: they read slots this barrier does not free
 #endif
-            slot = (slot + 1) & 3;
+            slot = slot1;
         });
         aoff ^= A_BYTES;
     }
