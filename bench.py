@@ -519,6 +519,18 @@ def main():
             f32["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows32[:4]]
             extras["fp32"] = f32
             del eng32
+            # ... and the same fp32 tensors with every conv product as three bf16 MFMAs (VToonifyEngine(x3=True), DESIGN.md
+            # 4.1i): the reference's precision (4e-5 of max|y| against the fp32 oracle, bar 1e-4) on the bf16 matrix cores
+            eng3 = VToonifyEngine(sd_dev, args.backbone, 256, torch.float32, dev, x3=True)
+            f3 = lanes_rate(1, H, W, 16, engine=eng3, note="fp32 tensors, convolutions as 3 bf16 MFMAs per product "
+                                                             "(operands split into bf16 head + remainder in registers)")
+            f3["single_stream"] = lanes_rate(1, H, W, 12, engine=eng3, n_lanes=1)["value"]
+            if B > 1:
+                f3["headline_batch"] = lanes_rate(B, H, W, 8, engine=eng3, note=f"{B} frames per step like `value`")
+            rows3, roof3 = kernel_table(eng3, eng3.plan_for(1, H, W, True, d_s != 0.0), torch.float32, 2)
+            f3["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows3[:6]]
+            extras["fp32x3"] = f3
+            del eng3
         # the headline workload with plans from the per-image geometry only (VT_BATCH_EXACT=1: a frame inside a batch equals
         # the frame alone bit for bit): fresh engine, the switch is read when its plans are built
         if B > 1 and os.environ.get("VT_BATCH_EXACT") != "1":

@@ -34,9 +34,15 @@
 extern "C" {
 #endif
 
-#define VT_ABI_VERSION 4
+#define VT_ABI_VERSION 5
 
-enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2,
+       /* vt_conv_desc.dtype only (ABI 5): fp32 tensors and weights in memory exactly as VT_F32, but the contraction may run on
+        * the bf16 matrix cores as three terms per product (bf16 head / remainder split of both operands in registers, fp32
+        * accumulate; ~4e-5 of max|y| end to end against fp32).  The reference's fp32 convolutions (cuDNN behind
+        * op/conv2d_gradfix.py:34-42, F.conv2d in model/vtoonify.py:92-128) at matrix-core speed; kernel instances without
+        * that form run exact fp32.  out_dtype stays VT_F32 / VT_BF16. */
+       VT_F32X3 = 3 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
 
 /* activation codes of the fused epilogues */
@@ -122,7 +128,7 @@ typedef struct vt_conv_desc {
     int32_t ld_out;        /* NHWC: per-pixel stride in elements; NCHW: ignored */
     int32_t out_layout;    /* VT_OUT_NHWC / VT_OUT_NCHW */
     int32_t out_dtype;     /* VT_F32 / VT_BF16 (NCHW output is always fp32) */
-    int32_t dtype;         /* VT_F32 / VT_BF16: dtype of src*, weight */
+    int32_t dtype;         /* VT_F32 / VT_BF16: dtype of src*, weight; VT_F32X3: fp32 tensors, bf16 x 3 products (above) */
     int32_t tile_hint;     /* 0 = auto; otherwise SPLITK*1000000 + BM*1000 + BN of a compiled tile
                               (SPLITK 0 = auto); +1000000000 forces the register-staged
                               loader where the direct-to-LDS one would apply */

@@ -29,7 +29,7 @@ def test_gfx950_library_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} not exported by {path}"
     lib.vt_abi_version.restype = ctypes.c_int
-    assert lib.vt_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.vt_abi_version() == _lib.ABI_VERSION == 5
     lib.vt_build_target.restype = ctypes.c_char_p
     assert lib.vt_build_target() == b"gfx950"
 

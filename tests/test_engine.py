@@ -32,12 +32,12 @@ BB = {"D": "dualstylegan", "T": "toonify"}
 _cache = {}
 
 
-def engine(tag, dtype, dev):
-    key = (tag, dtype, str(dev))
+def engine(tag, dtype, dev, x3=False):
+    key = (tag, dtype, str(dev), x3)
     if key not in _cache:
         _cache.clear()  # one resident engine at a time (D is 666 MB of fp32 weights)
         sd = synth.synth_state_dict(load_keys(tag), 0)
-        _cache[key] = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, BB[tag], 256, dtype, dev)
+        _cache[key] = VToonifyEngine({k: v.to(dev) for k, v in sd.items()}, BB[tag], 256, dtype, dev, x3=x3)
     return _cache[key]
 
 
@@ -84,6 +84,23 @@ def test_golden_fp32(dev, tag):
     y2 = eng.forward(torch.from_numpy(d["x2"]).to(dev), torch.from_numpy(d["style2"]).to(dev), 0.75)
     check(y2, d["y2_ds0.75"], torch.float32, "per-sample styles")
     check(eng.map_style(torch.from_numpy(d["zplus"]).to(dev)), d["wplus"], torch.float32, "zplus2wplus")
+
+
+def test_golden_f32x3(dev):
+    """The fp32 engine with its convolutions as three bf16 MFMAs per product (VToonifyEngine(x3=True), vt_conv_desc.dtype =
+    VT_F32X3) against the REFERENCE's golden frame: the fp32 bar (1e-4 of max|ref|) holds -- measured 2-4e-5 --
+    and the result is not the exact-fp32 engine's (the f32x3 instances ran)."""
+    d, _ = load_golden("e2e_D.npz")
+    eng = engine("D", torch.float32, dev, x3=True)
+    x, s = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["style"]).to(dev)
+    y = eng.forward(x, s, 0.5).clone()
+    check(y, d["y_ds0.5"], torch.float32, "y_ds0.5 f32x3")
+    feat, skip = eng.forward(x, s, 0.5, return_feat=True)
+    check(feat, d["feat_ds0.5"], torch.float32, "feat f32x3")
+    e3 = rel_err(y.float().cpu().numpy(), d["y_ds0.5"])
+    assert e3 > 0.0
+    kinds = {info["kernel"] for _, _, info in eng.frame_ops(eng.plan_for(1, x.shape[2], x.shape[3], True, True)) if isinstance(info, dict)}
+    assert any(k.startswith("conv_") for k in kinds)
 
 
 @pytest.mark.parametrize("tag", ["D", "T"])
@@ -206,6 +223,10 @@ def test_full_size_fp32_vs_oracle(tag, hw):
     check(y, ref, torch.float32, f"{tag} {hw}")
     yb = engine(tag, torch.bfloat16, dev).forward(x.to(dev), s.to(dev), 0.5)
     check(yb, ref, torch.bfloat16, f"{tag} {hw} bf16")
+    # the fp32 engine on the bf16 matrix cores (three bf16 MFMAs per product): the same 1e-4 bar
+    y3 = engine(tag, torch.float32, dev, x3=True).forward(x.to(dev), s.to(dev), 0.5)
+    check(y3, ref, torch.float32, f"{tag} {hw} f32x3")
+    assert not torch.equal(y3, y)
 
 
 @pytest.mark.gpu

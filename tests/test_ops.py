@@ -624,6 +624,52 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
         assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < (F32_TOL if dtype == torch.float32 else 8e-3)
 
 
+def test_conv_f32x3(dev):
+    """vt_conv_desc.dtype = VT_F32X3 (ABI 5): fp32 tensors, every product as three bf16 MFMAs (bf16 head / remainder split of
+    both operands in the fragment registers).  Patch tiles, the direct-to-LDS 1-D kernel (stride 2) and the whole-K kernel
+    (fragment stream) against the fp32 oracle at 3e-5 of max|y| -- and NOT bit-equal to the exact-fp32 instance, i.e. the
+    f32x3 instance really ran; a conv whose kernel has no such instance (thin outputs) runs exact fp32."""
+    import ctypes
+    from vtoonify_amd import _lib
+    g = np.random.default_rng(77)
+    cases = [  # N, cin, H, W, cout, stride, dil, hint, stream, expect_x3
+        (2, 64, 19, 37, 72, 1, 1, 0, False, True),                   # patch, auto plan
+        (1, 96, 21, 35, 136, 1, 1, P + 256128, False, True),         # 256 x 128 patch tiles, 3 chunks
+        (1, 64, 13, 18, 72, 2, 1, 0, False, True),                   # stride 2: 1-D direct-to-LDS kernel
+        (2, 256, 9, 11, 136, 1, 1, 0, True, True),                   # whole-K kernel (one round of 8 x 32 channels)
+        (1, 256, 12, 10, 40, 1, 2, 4 * P, True, True),               # whole-K, dilated, forced by hint
+        (1, 64, 9, 9, 3, 1, 1, 0, False, False),                     # thin outputs: exact fp32
+    ]
+    for N, cin, H, W, cout, stride, dil, hint, stream, expect_x3 in cases:
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        pad = dil
+        Ho, Wo = (H + 2 * pad - 2 * dil - 1) // stride + 1, (W + 2 * pad - 2 * dil - 1) // stride + 1
+        xt = K.nchw_to_nhwc(T(x, dev), torch.float32)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=torch.float32)
+        wst = K.conv_weight_stream(wp) if stream else None
+        ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+        planar = cout <= 3
+
+        def run(dt):
+            if planar:
+                out = torch.zeros((N, cout, Ho, Wo), dtype=torch.float32, device=dev)
+                okw = dict(out=out, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32)
+            else:
+                out = torch.zeros((N, Ho, Wo, (cout + 7) // 8 * 8), dtype=torch.float32, device=dev)
+                okw = dict(out=out, ld_out=out.shape[3], out_dtype=K.VT_F32)
+            K.conv2d(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=Ho, out_w=Wo, weight=wp, cout=cout, kh=3, kw=3,
+                     stride=stride, pad=pad, dil=dil, bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, dtype=dt,
+                     tile_hint=hint, splitk_ws=ws, weight_stream=wst, **okw)
+            return out if planar else out.permute(0, 3, 1, 2)[:, :cout]
+        y3, y1 = run(K.VT_F32X3), run(K.VT_F32)
+        ref = O.leaky_relu(O.conv2d(x, w, b, stride, pad, dil), 0.2) * np.float32(2 ** 0.5)
+        assert rel_err(y1.cpu().numpy(), ref) < F32_TOL
+        assert rel_err(y3.cpu().numpy(), ref) < 3e-5, (cin, H, W, cout, stride, dil, hint)
+        assert torch.equal(y3, y1) != expect_x3, (cin, H, W, cout, stride, dil, hint)
+
+
 def test_conv_batch_invariance(dev):
     """Tile / split-K choices depend on the per-image geometry only, so a frame convolved inside a
     batch is BIT-identical to the same frame alone (video path: s_w.repeat(B,1,1))."""

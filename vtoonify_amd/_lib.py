@@ -15,8 +15,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
-ABI_VERSION = 4   # VT_ABI_VERSION of include/vtoonify_amd.h
+ABI_VERSION = 5   # VT_ABI_VERSION of include/vtoonify_amd.h
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
+VT_F32X3 = 3   # vt_conv_desc.dtype only: fp32 tensors, products as three bf16 MFMAs (include/vtoonify_amd.h)
 ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_NCHW = 0, 1
 

@@ -273,24 +273,49 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
         }
         u128 fa[2][4];
         read_a(fa[0], 0);
+        u128 wk0 = zero128(), wk1 = zero128();   // f32x3: the even half-step's weight fragments, kept for the odd one
 #pragma unroll
         for (int st = 0; st < NSUB; ++st) {
             // loads issued after sub-step st's pair: the refills of the following min(DEPTH-1, NSUB-1-st) sub-steps
             constexpr int AHEAD = FK_DEPTH - 1;
             if (st >= FK_DEPTH) fk_wait_pairs<AHEAD>(NSUB - 1 - st < AHEAD ? NSUB - 1 - st : AHEAD);
-            const u128 w0 = wr[st % FK_DEPTH][0], w1 = wr[st % FK_DEPTH][1];
+            // (f32x3 runs VALU work on the pair: vt_settled ties it to the wait above; the MFMA-only forms keep the
+            // instruction stream they were tuned and validated with)
+            const u128 w0 = is_x3<T>::value ? vt_settled(wr[st % FK_DEPTH][0]) : wr[st % FK_DEPTH][0];
+            const u128 w1 = is_x3<T>::value ? vt_settled(wr[st % FK_DEPTH][1]) : wr[st % FK_DEPTH][1];
             if (st + FK_DEPTH < NSUB)
                 vt_gload16_pair_hidden<FK_AUX>(wr[st % FK_DEPTH][0], wr[st % FK_DEPTH][1], wcur + (st + FK_DEPTH) * 2048,
                                                wlane);
-            if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (p.dbg == 21) {   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): operands fetched, no MFMA
-                    acc[a][0][0] += vt_u2f(w0.x ^ fa[st & 1][a].x);
-                    acc[a][1][0] += vt_u2f(w1.x ^ fa[st & 1][a].x);
+            if constexpr (is_x3<T>::value) {
+                // f32x3 (conv_igemm.hip): a tap's two half-steps carry the 16-byte chunks q and 4+q of the 32-channel row, for
+                // pixels (fa[0], fa[1]) and weights (even / odd stream pair) alike: one bf16 fragment after the split
+                if ((st & 1) == 0) {
+                    wk0 = w0, wk1 = w1;
+                    read_a(fa[1], st + 1);
                 } else {
-                    Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
-                    Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
+                    u128 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) x3_split(fa[0][a], fa[1][a], ah[a], al[a]);
+                    x3_split(wk0, w0, bh[0], bl[0]);
+                    x3_split(wk1, w1, bh[1], bl[1]);
+                    if (st + 1 < NSUB) read_a(fa[0], st + 1);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        Mma<f32x3_t>::run3(acc[a][0], bh[0], bl[0], ah[a], al[a]);
+                        Mma<f32x3_t>::run3(acc[a][1], bh[1], bl[1], ah[a], al[a]);
+                    }
+                }
+            } else {
+                if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (p.dbg == 21) {   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): operands fetched, no MFMA
+                        acc[a][0][0] += vt_u2f(w0.x ^ fa[st & 1][a].x);
+                        acc[a][1][0] += vt_u2f(w1.x ^ fa[st & 1][a].x);
+                    } else {
+                        Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
+                        Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
+                    }
                 }
             }
         }
@@ -487,6 +512,13 @@ int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
         const char* e = getenv("VT_FULLK_AUX");
         return e ? atoi(e) : 0;
     }();
+    if constexpr (sizeof(T) == 4 && !is_x3<T>::value) {
+        if (a.x3) {   // f32x3 instance (conv_igemm.hip, "f32x3")
+            auto k = conv_fullk_kernel<f32x3_t, FK_DEPTH_DEFAULT>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
+            return vt_check_launch("vt_conv2d(whole-K, f32x3)");
+        }
+    }
     if (depth == 9) {
         auto k = conv_fullk_kernel<T, 9>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);

@@ -88,6 +88,7 @@ struct ConvArgs {
     int rgb_only;               // vt_conv_desc.rgb_only: the C-channel output is not stored (fused ToRGB only)
     int in_absdiff;             // vt_conv_desc.in_absdiff: input = cat[src0, |src0 - src1|] (thin kernel)
     int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
+    int x3;             // vt_conv_desc.dtype == VT_F32X3: fp32 tensors, products as three bf16 MFMAs where the instance exists
 };
 
 template <typename T>
@@ -122,6 +123,77 @@ struct Mma<float> {
 #endif
     }
 };
+
+// ---------------------------------------------------------------------------------------
+// f32x3: fp32 operands on the bf16 matrix cores (round 4).  The reference computes fp32
+// (model/stylegan/op/upfirdn2d_kernel.cu:311, fused_bias_act_kernel.cu:96, cuDNN fp32 convs); the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate.  Here every fp32 operand x is split ON THE FLY, in the
+// fragment registers, into its bf16 head h = rne_bf16(x) and the bf16-rounded remainder l = rne_bf16(x - h)
+// (|x - h - l| <= 2^-17 |x|), and a product a*b becomes ah*bh + al*bh + ah*bl on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation (the dropped al*bl is <= 2^-16 |a*b|): 3 matrix instructions of 16 cycles per 32-channel row instead
+// of 8 of 32 cycles.  Tensors and weights stay plain fp32 in memory -- the mode is a property of the launch
+// (vt_conv_desc.dtype = VT_F32X3), any conv whose kernel instance has no f32x3 form simply runs exact fp32.
+// Lane group q of a fragment takes the 16-byte chunks q and 4+q of a 128-byte row (channels 4q..4q+3 and
+// 16+4q..16+4q+3) for BOTH operands, so the K positions pair up whatever the order.
+// End-to-end against the fp32 oracle: 4e-5 of max|y| (bar 1e-4; exact-fp32 MFMA: 5e-6) -- tests/test_engine.py.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct is_x3 {
+    static constexpr bool value = false;
+};
+template <>
+struct is_x3<f32x3_t> {
+    static constexpr bool value = true;
+};
+__device__ __forceinline__ void x3_split(const u128& x, const u128& y, u128& hi, u128& lo) {
+    auto pair = [](uint32_t a, uint32_t b, uint32_t& h, uint32_t& l) {
+        const float fa = vt_u2f(a), fb = vt_u2f(b);
+        h = pack_bf16x2(fa, fb);
+        l = pack_bf16x2(fa - vt_u2f(h << 16), fb - vt_u2f(h & 0xffff0000u));
+    };
+    pair(x.x, x.y, hi.x, lo.x);
+    pair(x.z, x.w, hi.y, lo.y);
+    pair(y.x, y.y, hi.z, lo.z);
+    pair(y.z, y.w, hi.w, lo.w);
+}
+template <>
+struct Mma<f32x3_t> {   // on already split operands: (weights head, weights remainder) x (pixels head, pixels remainder)
+    static __device__ __forceinline__ void run3(f32x4& acc, const u128& wh, const u128& wl, const u128& ah, const u128& al) {
+        Mma<bf16_t>::run(acc, wh, ah);
+        Mma<bf16_t>::run(acc, wh, al);
+        Mma<bf16_t>::run(acc, wl, ah);
+    }
+};
+// One 128-byte K row of a wave tile: acc[a][b] += W_b . A_a over the row's channels.  `pa(a, sub)` / `pb(b, sub)` give
+// the LDS address of the 16-byte chunk (sub * 4 + q) of pixel fragment a / weight fragment b.  bf16 / fp32: the two
+// half-row steps of the kernels' original loops, verbatim; f32x3: both halves, split, three products.
+template <typename T, int TM, int TN, typename PA, typename PB>
+__device__ __forceinline__ void mma_row(f32x4 (&acc)[TM][TN], PA&& pa, PB&& pb) {
+    if constexpr (is_x3<T>::value) {
+        u128 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) x3_split(ld128(pa(a, 0)), ld128(pa(a, 1)), ah[a], al[a]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) x3_split(ld128(pb(b, 0)), ld128(pb(b, 1)), bh[b], bl[b]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) Mma<f32x3_t>::run3(acc[a][b], bh[b], bl[b], ah[a], al[a]);
+    } else {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            u128 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = ld128(pa(a, sub));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = ld128(pb(b, sub));
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
+        }
+    }
+}
 
 // x' = x * scale + shift on one 16-byte vector (AdaIN prologue)
 template <typename T>
@@ -922,6 +994,11 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
             issue(issued, nbuf);
             ++issued;
         }
+        if constexpr (is_x3<T>::value) {
+            mma_row<T, TM, TN>(acc,
+                               [&](int a, int sub) { return sA(buf) + (a_row0 + a * 16) * 128 + (((sub * 4 + q) ^ l7) << 4); },
+                               [&](int b, int sub) { return sB(buf) + (b_row0 + b * 16) * 128 + (((sub * 4 + q) ^ l7) << 4); });
+        } else {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int phys = ((sub * 4 + q) ^ l7) << 4;
@@ -937,6 +1014,7 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
                     if (DBG == 1) acc[a][b][0] += vt_u2f(fa[a].x ^ fb[b].x);  // ablation: LDS reads kept, no MFMA
                     else Mma<T>::run(acc[a][b], fb[b], fa[a]);
                 }
+        }
         }
         // step kt+1 must have landed (in every wave) before anyone reads it; step kt's buffer may
         // be overwritten by the next issue once every wave has finished reading it
@@ -1115,6 +1193,14 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
             a_age = 0;
         }
         const int ky = tap / 3, kx = tap - ky * 3;
+        if constexpr (is_x3<T>::value) {
+            mma_row<T, TM, TN>(acc,
+                               [&](int a, int sub) {
+                                   const int pr = (wm * TM + a + ky * DIL) * PW + kx * DIL + l15;
+                                   return sA(abuf) + pr * 128 + (((sub * 4 + q) ^ (pr & 7)) << 4);
+                               },
+                               [&](int b, int sub) { return sB(bbuf) + (b_row0 + b * 16) * 128 + (((sub * 4 + q) ^ l7) << 4); });
+        } else {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int slot = sub * 4 + q;
@@ -1130,6 +1216,7 @@ conv_patch_kernel(const ConvArgs p, const GldsArgs g) {
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
+        }
         }
         // Before step s+1 is read its weights must have landed (and, at a chunk boundary, the next
         // patch).  Loads younger than B(s+1): B(s+2..issued-1) and a patch issued in step s-1 or s
@@ -1678,23 +1765,15 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
         // (128x128: 2 stages; 128x64 / 64x128: 3; 64x64 and smaller: 4)
         constexpr int STAGE = ((BM + 31) / 32 + (BN + 31) / 32) * 32 * 128;
         constexpr int NST = STAGE * 4 <= 80 * 1024 ? 4 : STAGE * 3 <= 80 * 1024 ? 3 : 2;
-        const char* dbg = getenv("VT_CONV_ABLATE");  // tools/conv_bench.py ablations only
-        if (BM == 128 && BN == 128 && dbg && dbg[0] == '1') {
-            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 1 : 0>;
-            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
-        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '2') {
-            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 2 : 0>;
-            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
-        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '3') {
-            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 3 : 0>;
-            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
-        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '4') {
-            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 4 : 0>;
-            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
-        } else if (BM == 128 && BN == 128 && dbg && dbg[0] == '5') {
-            auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST, (BM == 128 && BN == 128) ? 5 : 0>;
-            VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
-        } else {
+        bool done = false;
+        if constexpr (sizeof(T) == 4 && !is_x3<T>::value) {
+            if (a.x3) {   // f32x3 instance of the same tile (conv_igemm.hip, "f32x3")
+                auto k = conv_igemm_glds_kernel<f32x3_t, BM, BN, WM, WN, NST>;
+                VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
+                done = true;
+            }
+        }
+        if (!done) {
             auto k = conv_igemm_glds_kernel<T, BM, BN, WM, WN, NST>;
             VT_LAUNCH(k, dim3((unsigned)tiles), dim3(256), stream, args, g);
         }
@@ -2031,8 +2110,18 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         return VT_ERR_UNSUPPORTED;
     }
     if (args.phase != 2) {
-        auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL, NSTB, ABUF>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        bool done = false;
+        if constexpr (sizeof(T) == 4 && !is_x3<T>::value && DIL == 1) {
+            if (a.x3) {   // f32x3 instance of the same tile
+                auto k = conv_patch_kernel<f32x3_t, TH, BN, WM, WN, DIL, NSTB, ABUF>;
+                VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+                done = true;
+            }
+        }
+        if (!done) {
+            auto k = conv_patch_kernel<T, TH, BN, WM, WN, DIL, NSTB, ABUF>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        }
     }
     int rc = vt_check_launch("vt_conv2d(patch)");
     if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
@@ -2219,7 +2308,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // software-pipelined form of the 256-pixel tiles (conv_patch_pipe.hpp; same K order, same bits).
             // VT_PATCH_PIPE=0: the per-tap form below (A/B; read per call: tests flip it)
             const char* e = getenv("VT_PATCH_PIPE");
-            const bool pipe = !(e && e[0] == '0');
+            const bool pipe = !(e && e[0] == '0') && !a.x3;   // (f32x3 runs the per-tap form: its instances live there)
             if constexpr (sizeof(T) == 2) {   // A/B + ablations (tools/conv_bench.py; removed once measured)
                 const bool big = pipe && e && a.dil == 1 && t.bm == 256 && t.bn == 128;
                 if (big && e[0] == '2') return launch_patchp<T, 16, 128, 4, 2, 4, 1>(a, g, stream);
@@ -2281,12 +2370,13 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
 static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     VT_REQUIRE(d, "vt_conv2d: null descriptor");
     VT_REQUIRE(d->src0 && d->weight && d->out, "vt_conv2d: null tensor");
-    VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv2d: dtype must be fp32 or bf16");
+    VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16 || d->dtype == VT_F32X3, "vt_conv2d: dtype must be fp32, bf16 or f32x3");
+    const int cdt = d->dtype == VT_F32X3 ? VT_F32 : d->dtype;   // storage type of src*, weight
     VT_REQUIRE(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 >= 0 && d->c1 % 8 == 0,
                "vt_conv2d: channel counts must be multiples of 8 (got %d,%d)", d->c0, d->c1);
     VT_REQUIRE(d->c1 == 0 || d->src1, "vt_conv2d: c1 > 0 but src1 is null");
     VT_REQUIRE(d->ld0 >= d->c0 && (d->c1 == 0 || d->ld1 >= d->c1), "vt_conv2d: pixel stride < channels");
-    const int esz = d->dtype == VT_F32 ? 4 : 2;
+    const int esz = cdt == VT_F32 ? 4 : 2;
     VT_REQUIRE(((uintptr_t)d->src0 % 16 == 0) && ((int64_t)d->ld0 * esz % 16 == 0) &&
                    ((uintptr_t)d->weight % 16 == 0),
                "vt_conv2d: src0/weight must be 16-byte aligned with 16-byte pixel stride");
@@ -2303,8 +2393,8 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
                    (int64_t)d->n * d->out_h * d->out_w * (d->phases == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "vt_conv2d: tensor too large for 32-bit pixel indices");
 
-    VT_REQUIRE(!d->stats_part || (d->phases == 1 && d->out_layout == VT_OUT_NHWC && d->out_dtype == d->dtype &&
-                                  d->cout % 8 == 0 && (d->dtype == VT_BF16 || d->dtype == VT_F32)),
+    VT_REQUIRE(!d->stats_part || (d->phases == 1 && d->out_layout == VT_OUT_NHWC && d->out_dtype == cdt &&
+                                  d->cout % 8 == 0 && (cdt == VT_BF16 || cdt == VT_F32)),
                "vt_conv2d: stats_part needs phases == 1, NHWC output in the compute dtype, cout %% 8 == 0");
     VT_REQUIRE(!d->post_relu || !d->rgb_weight, "vt_conv2d: post_relu cannot be combined with the fused ToRGB");
     VT_REQUIRE(!d->rgb_weight || (d->rgb_out && d->phases == 1 && d->out_layout == VT_OUT_NHWC && !d->transposed),
@@ -2324,6 +2414,7 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
         const char* e = getenv("VT_RGB_ABLATE");
         a.dbg = e ? atoi(e) : 0;
     }
+    a.x3 = d->dtype == VT_F32X3 ? 1 : 0;
     a.alpha_dev = d->alpha_dev;
     a.post_relu = d->post_relu ? 1 : 0;
     a.wstream = d->weight_stream;
@@ -2388,12 +2479,13 @@ extern "C" int vt_conv2d(const vt_conv_desc* d, vt_stream stream) {
     if (rc != VT_OK) return rc;
     const int64_t wsf = (d->splitk_ws && d->splitk_ws_bytes > VT_TICKET_BYTES) ? (d->splitk_ws_bytes - VT_TICKET_BYTES) / 4 : 0;
     g_stats_emitted = false;
+    a.x3 = d->dtype == VT_F32X3;
     const int rcl = d->dtype == VT_BF16 ? dispatch<bf16_t>(a, d->tile_hint, wsf, stream)
                                         : dispatch<float>(a, d->tile_hint, wsf, stream);
     if (rcl != VT_OK || !a.stats_part || g_stats_emitted || d->splitk_phase == 1) return rcl;
     // the plan had no reduce pass to carry the statistics: append the stand-alone launch
     return vt_internal_instnorm_partial(a.stats_part, d->out, d->ld_out, d->n, d->out_h * d->out_w, d->cout,
-                                        d->dtype, stream);
+                                        d->dtype == VT_F32X3 ? VT_F32 : d->dtype, stream);
 }
 
 extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {

@@ -108,6 +108,20 @@ __device__ __forceinline__ f16_t from_f32<f16_t>(float f) {
     return r;
 }
 
+// fp32 tensors whose products run on the bf16 matrix cores as three terms (hi*hi + hi*lo + lo*hi of the bf16 head /
+// remainder split of both operands, fp32 accumulate): element type tag of the conv kernels' "f32x3" instances
+// (vt_conv_desc.dtype == VT_F32X3).  In memory it IS a float.
+struct f32x3_t {
+    float v;
+};
+__device__ __forceinline__ float to_f32(f32x3_t x) { return x.v; }
+template <>
+__device__ __forceinline__ f32x3_t from_f32<f32x3_t>(float f) {
+    f32x3_t r;
+    r.v = f;
+    return r;
+}
+
 // 16-byte vector of T
 template <typename T>
 struct Vec16 {
@@ -141,6 +155,10 @@ __device__ __forceinline__ void unpack16<float>(u128 v, float* f) {
     f[3] = vt_u2f(v.w);
 }
 template <>
+__device__ __forceinline__ void unpack16<f32x3_t>(u128 v, float* f) {
+    unpack16<float>(v, f);
+}
+template <>
 __device__ __forceinline__ void unpack16<bf16_t>(u128 v, float* f) {
     f[0] = vt_u2f(v.x << 16);
     f[1] = vt_u2f(v.x & 0xffff0000u);
@@ -168,6 +186,10 @@ __device__ __forceinline__ u128 pack16<float>(const float* f) {
     v.z = vt_f2u(f[2]);
     v.w = vt_f2u(f[3]);
     return v;
+}
+template <>
+__device__ __forceinline__ u128 pack16<f32x3_t>(const float* f) {
+    return pack16<float>(f);
 }
 // two fp32 -> packed bf16 pair, round-to-nearest-even (one v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -350,6 +372,21 @@ __device__ __forceinline__ void vt_vmcnt_fence() {
     static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
     __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+// The value of a hidden load's destination AFTER its vt_vmcnt_fence: an empty volatile asm that "rewrites" the registers.
+// Volatile asm statements keep their order, so every consumer of the result is data-dependent on a statement that comes
+// after the wait -- without it only the machine scheduler's barrier holds register-only consumers below the wait, and
+// instruction selection may already have emitted pure VALU work on the registers above it (seen on the f32x3 whole-K
+// kernel: its bf16 splits of the next weight pair moved above the counted wait and read registers the load had not
+// written yet -- NaNs on a cold first launch, clean reruns).
+#ifdef VT_EMU
+static inline u128 vt_settled(const u128& v) { return v; }
+#else
+__device__ __forceinline__ u128 vt_settled(const u128& v) {
+    vt_u32x4 x = __builtin_bit_cast(vt_u32x4, v);
+    asm volatile("" : "+v"(x));
+    return __builtin_bit_cast(u128, x);
 }
 #endif
 

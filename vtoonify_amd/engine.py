@@ -64,13 +64,17 @@ class VToonifyEngine:
 
     state_dict: the reference's `g_ema` schema, fp32, on `device`.
     dtype: torch.bfloat16 (fast) or torch.float32 (parity mode, exact-fp32 MFMA).
+    x3 (fp32 only): the convolutions run as three bf16 MFMAs per fp32 product (vt_conv_desc.dtype = VT_F32X3: operands split
+    into bf16 head + remainder in the fragment registers, fp32 accumulate) -- every tensor, weight and non-conv kernel stays
+    fp32.  4e-5 of max|y| against the fp32 oracle (bar 1e-4) instead of 5e-6; the reference's precision at several times
+    the speed of the exact-fp32 matrix instructions.
     """
     supports_borrow = True   # forward(..., borrow=True) hands out the plan's output buffer instead of a copy
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "dualstylegan",
                  in_size: int = 256, dtype: torch.dtype = torch.bfloat16,
                  device: Optional[torch.device] = None, cache_styles: bool = False,
-                 tile_hints: Optional[Dict[str, int]] = None, style_gate: bool = False):
+                 tile_hints: Optional[Dict[str, int]] = None, style_gate: bool = False, x3: bool = False):
         assert backbone in ("dualstylegan", "toonify")
         assert dtype in (torch.bfloat16, torch.float32)
         self.backbone = backbone
@@ -78,6 +82,8 @@ class VToonifyEngine:
         self.in_size = in_size
         self.dtype = dtype
         self.dt = K.dt_code(dtype)
+        self.x3 = bool(x3) and dtype == torch.float32
+        self.dt_conv = K.VT_F32X3 if self.x3 else self.dt   # vt_conv_desc.dtype; everything else sees self.dt
         self.esz = 2 if dtype == torch.bfloat16 else 4
         any_t = next(iter(state_dict.values()))
         self.device = torch.device(device) if device is not None else any_t.device
@@ -238,7 +244,7 @@ class VToonifyEngine:
         wt = kw.get("weight")
         if isinstance(wt, torch.Tensor) and wt.data_ptr() in self._wstream:
             kw["weight_stream"] = self._wstream[wt.data_ptr()]
-        d = self._apply_hint(K.make_conv_desc(dtype=self.dt, **kw))
+        d = self._apply_hint(K.make_conv_desc(dtype=self.dt_conv, **kw))
         plan.keep.append(d)
         cin = d.c0 + d.c1
         m = d.n * d.out_h * d.out_w
@@ -264,7 +270,7 @@ class VToonifyEngine:
         wt = kw.get("weight")
         if isinstance(wt, torch.Tensor) and wt.data_ptr() in self._wstream:
             kw["weight_stream"] = self._wstream[wt.data_ptr()]
-        d = self._apply_hint(K.make_conv_desc(dtype=self.dt, **kw))
+        d = self._apply_hint(K.make_conv_desc(dtype=self.dt_conv, **kw))
         d.splitk_ws, d.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist"
         tile = self.lib.vt_conv2d_tile(C.byref(d))
         return tile // 100000000 if tile >= 0 else -1
@@ -771,7 +777,7 @@ class VToonifyEngine:
                 rgb_kw = dict(rgb_weight=wm3, rgb_bias=self.w[f"{n3}.bias"], rgb_resid=rgb_ptr, rgb_out=rgb_ptr)
                 # ToRGB (1x1 modulated conv, no demod, + bias + up-sampled skip; model.py:383-392) is
                 # fused into the StyledConv's epilogue when one tile holds all its channels
-                probe = self._apply_hint(K.make_conv_desc(dtype=self.dt, **same_kw, **rgb_kw))
+                probe = self._apply_hint(K.make_conv_desc(dtype=self.dt_conv, **same_kw, **rgb_kw))
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC, VT_BF16, VT_F16, VT_F32, ConvDesc
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC, VT_BF16, VT_F16, VT_F32, VT_F32X3, ConvDesc
 
 _DT = {torch.float32: VT_F32, torch.bfloat16: VT_BF16, torch.float16: VT_F16}
 
@@ -113,7 +113,7 @@ def make_conv_desc(*, src0, c0, ld0, n, h, w, out_h, out_w, weight, cout, kh, kw
     d.out, d.ld_out = _ptr(out), ld_out
     d.out_layout = out_layout
     d.dtype = dtype
-    d.out_dtype = dtype if out_dtype is None else out_dtype
+    d.out_dtype = (VT_F32 if dtype == VT_F32X3 else dtype) if out_dtype is None else out_dtype   # (f32x3: fp32 tensors)
     d.tile_hint = tile_hint
     d.slope_vec = _ptr(slope_vec)
     d.rgb_weight, d.rgb_bias, d.rgb_resid, d.rgb_out = _ptr(rgb_weight), _ptr(rgb_bias), _ptr(rgb_resid), _ptr(rgb_out)
