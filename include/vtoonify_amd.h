@@ -450,18 +450,6 @@ int vt_gru_blend(void* h, int ld_h, const void* z, const void* q, int64_t rows, 
 int vt_coords_from_flow(float* coords, const float* flow, int n, int h, int w, vt_stream stream);
 int vt_convex_upsample(float* out, const float* flow, const float* mask, int n, int h, int w, vt_stream stream);
 
-/* ---------------------------------------------------------------------------------
- * Fusion.forward's gate in one launch (model/vtoonify.py:122-128, VToonify-D): given the AdaIN scale / shift of
- * vt_instnorm_stats over cat[f_G, |f_G - f_E|] (n, 2c each),
- *   mask (n,1,h,w) fp32 = tanh(relu(conv3x3_{2c->1}(scale * cat[f_G, |f_G - f_E|] + shift) + bias))
- *   fem  (n,h,w,ld_fem)  = [skip(3) | zeros | f_E * mask]     (header = ld_fem - c channels; NULL: mask only)
- * -- what vt_affine_apply -> vt_conv2d(cout 1) -> vt_fusion_pack computed in three launches.  f_g / f_e NHWC in the
- * compute dtype; weight packed [1][9][2c] (vt_pack_conv_weight); skip (n,3,h,w) fp32.
- * --------------------------------------------------------------------------------- */
-int vt_fusion_gate(float* mask, void* fem, int ld_fem, const void* f_g, int ld_g, const void* f_e, int ld_e,
-                   const float* scale, const float* shift, const void* weight, const float* bias,
-                   const float* skip, int n, int h, int w, int c, int dtype, vt_stream stream);
-
 /* Layout converters at the boundary (frames arrive NCHW fp32, model/vtoonify.py:210). */
 int vt_nchw_to_nhwc(void* out, int ld_out, const void* in, int n, int c, int hw,
                     int in_dtype, int out_dtype, vt_stream stream);

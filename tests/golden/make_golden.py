@@ -233,7 +233,22 @@ def gen_e2e():
         save(f"e2e_{tag}.npz", **out)
 
 
+def gen_e2e_mid():
+    """Mid-size, ragged pin of the oracle: VToonify-D, batch 2, 72 x 104 (9 x 13-pixel trunk, levels whose
+    sizes are not multiples of any tile), two different styles, d_s = 0.5 -- every full-size GPU comparison is HIP vs oracle,
+    so the oracle itself is checked against the reference at a size where tile edges and dilation borders matter.  Only
+    the inputs' seeds and the output are stored (x / style are regenerated from synth)."""
+    torch.manual_seed(0)
+    m = VToonify(backbone="dualstylegan").eval()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes, seed=0))
+    x = synth.synth_frames(2, 72, 104, seed=2024)
+    s = torch.cat([synth.synth_style(seed=15), synth.synth_style(seed=16)], 0)
+    y = m(x, s, d_s=0.5)
+    save("e2e_D_mid.npz", y_ds05=npy(y).astype(np.float32), seeds=np.array([2024, 15, 16]), hw=np.array([72, 104]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "modules", "e2e"]
+    which = sys.argv[1:] or ["upfirdn2d", "fused_act", "modules", "e2e", "e2e_mid"]
     for w in which:
         globals()["gen_" + w]()

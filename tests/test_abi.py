@@ -106,3 +106,30 @@ def test_hot_kernels_do_not_spill():
     bad = {k: v["scratch"] for k, v in table.items()
            if v["scratch"] > (128 if any(c in k for c in capped) else 0)}
     assert not bad, bad
+
+# every environment switch the product reads, as DESIGN.md section 8 documents them (49 switches, most of
+# them lost A/B arms, were a correctness surface nobody tested; round 4 deleted the dead arms)
+DOCUMENTED_SWITCHES = {
+    # meaning for a user of the package
+    "VTOONIFY_AMD_DTYPE", "VT_BATCH_EXACT", "VT_MAX_PLANS", "VT_TILE_HINTS", "VT_GRAPH_FIRST", "VT_STYLE_GATE", "VT_PATCH_PIPE",
+    "VT_FULLKW", "VT_RAFT_GRAPH",
+    # test hooks: force a kernel form that the heuristics only choose at sizes a CPU-emulated test cannot afford
+    "VT_C32_BLOCKS", "VT_UPBLUR_WGS", "VT_UPBLUR_TALL", "VT_UPBLUR_P8", "VT_UPBLUR_DB", "VT_FULLKW_MIN_G", "VT_FULLKW_G",
+    "VT_SPLITK_IN_LAUNCH", "VT_GATE_LOADER",
+}
+
+
+def test_product_reads_only_documented_switches():
+    import re
+    found = set()
+    root = os.path.join(REPO, "vtoonify_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                found |= set(re.findall(r'getenv\("(VT[A-Z0-9_]*)"\)', src))
+                found |= set(re.findall(r'environ(?:\.get\(|\[)"(VT[A-Z0-9_]*)"', src))
+    assert found <= DOCUMENTED_SWITCHES, sorted(found - DOCUMENTED_SWITCHES)
+    design = open(os.path.join(REPO, "DESIGN.md")).read()
+    missing = [s for s in sorted(found) if s not in design]
+    assert not missing, f"switches read by the product but not in DESIGN.md: {missing}"

@@ -230,6 +230,24 @@ def test_full_size_fp32_vs_oracle(tag, hw):
 
 
 @pytest.mark.gpu
+def test_mid_size_ragged_vs_reference_golden():
+    """HIP against the REFERENCE itself (not the oracle) at a mid-size ragged geometry: D, batch 2, 72 x 104, two styles
+    (tests/golden/e2e_D_mid.npz).  fp32 exact, fp32 on the bf16 matrix cores (f32x3) and bf16."""
+    from vtoonify_amd import _lib
+    _lib.use_library(_lib.DEFAULT_LIB)
+    dev = torch.device("cuda:0")
+    d, _ = load_golden("e2e_D_mid.npz")
+    sx, s0, s1 = (int(v) for v in d["seeds"])
+    h, w = (int(v) for v in d["hw"])
+    x = synth.synth_frames(2, h, w, seed=sx).to(dev)
+    s = torch.cat([synth.synth_style(seed=s0), synth.synth_style(seed=s1)], 0).to(dev)
+    ref = d["y_ds05"]
+    check(engine("D", torch.float32, dev).forward(x, s, 0.5), ref, torch.float32, f"D 2x({h},{w}) vs reference golden")
+    check(engine("D", torch.float32, dev, x3=True).forward(x, s, 0.5), ref, torch.float32, f"D 2x({h},{w}) f32x3 vs reference golden")
+    check(engine("D", torch.bfloat16, dev).forward(x, s, 0.5), ref, torch.bfloat16, f"D 2x({h},{w}) bf16 vs reference golden")
+
+
+@pytest.mark.gpu
 def test_config3_batch4_vs_oracle():
     """BASELINE config 3's per-rank step: D, 4 frames of 22x144x256 per call (the reference's --batch_size 4,
     style_transfer.py:35,176 `s_w.repeat(B,1,1)`), fp32 and bf16 vs the oracle, every frame of the batch."""
@@ -450,6 +468,9 @@ def test_engine_housekeeping_round3(dev, monkeypatch):
     # ---- the module: precision switch + fingerprint
     monkeypatch.delenv("VTOONIFY_AMD_DTYPE", raising=False)
     assert VToonify(backbone="toonify").compute_dtype == torch.float32
+    assert VToonify(backbone="toonify").exact_fp32 is False     # fp32 tensors, conv products as three bf16 MFMAs (f32x3)
+    monkeypatch.setenv("VTOONIFY_AMD_DTYPE", "fp32_exact")
+    assert VToonify(backbone="toonify").compute_dtype == torch.float32 and VToonify(backbone="toonify").exact_fp32 is True
     monkeypatch.setenv("VTOONIFY_AMD_DTYPE", "bf16")
     assert VToonify(backbone="toonify").compute_dtype == torch.bfloat16
     assert VToonify(backbone="toonify", compute_dtype=torch.float32).compute_dtype == torch.float32

@@ -119,6 +119,25 @@ def test_end_to_end(tag, bb, backend):
     assert rel_err(O.zplus2wplus(sd, d["zplus"], bb), d["wplus"]) < TOL
 
 
+def test_end_to_end_mid_size_ragged():
+    """The oracle against the REFERENCE at a mid-size, ragged geometry (tests/golden/e2e_D_mid.npz, make_golden.py::gen_e2e_mid):
+    VToonify-D, batch 2, 72 x 104 (a 9 x 13-pixel trunk, dilated convs across image borders, levels that no tile divides),
+    two styles.  The full-size GPU tests compare HIP with the oracle; this pins the oracle itself away from 32 x 32."""
+    d, _ = load_golden("e2e_D_mid.npz")
+    sd = synth.to_numpy_sd(synth.synth_state_dict(load_keys("D"), 0))
+    sx, s0, s1 = (int(v) for v in d["seeds"])
+    h, w = (int(v) for v in d["hw"])
+    x = synth.synth_frames(2, h, w, seed=sx).numpy()
+    s = np.concatenate([synth.synth_style(seed=s0).numpy(), synth.synth_style(seed=s1).numpy()], 0)
+    old = O.set_backend("torch")
+    try:
+        y = O.vtoonify_forward(sd, x, s, 0.5, "dualstylegan")
+    finally:
+        O.set_backend(old)
+    assert y.shape == d["y_ds05"].shape == (2, 3, 4 * h, 4 * w)
+    assert rel_err(y, d["y_ds05"]) < TOL
+
+
 def test_psp_encoder(backend):
     """oracle/psp_oracle.py vs the reference's GradualStyleEncoder (tests/golden/make_golden_psp.py)."""
     from oracle import psp_oracle as P

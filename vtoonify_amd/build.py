@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libvtoonify_amd.so"
 SOURCES = ["capi.hip", "fused_bias_act.hip", "upfirdn2d.hip", "style_ops.hip", "conv_igemm.hip",
-           "norm_glue.hip", "frame_io.hip", "parsing_glue.hip", "raft_corr.hip", "flow_ops.hip", "fusion_glue.hip"]
+           "norm_glue.hip", "frame_io.hip", "parsing_glue.hip", "raft_corr.hip", "flow_ops.hip"]
 ARCH = "gfx950"
 
 

@@ -87,13 +87,6 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
     const int hi = l15 >> 3, lo = l15 & 7;
     int tile_m, tile_n, split;
     decode_block(p, tile_m, tile_n, split);
-    if (p.dbg == 23 || p.dbg == 24) {   // ablation (tools/conv_bench.py): G weight tiles per XCD-contiguous group
-        const int G = p.dbg == 23 ? 4 : p.tiles_n;   // default placement = 1 (a weight tile is shared by tiles_m WGs)
-        const int L = tile_n * p.tiles_m + tile_m;
-        const int grp = L / (p.tiles_m * G), idx = L - grp * (p.tiles_m * G);
-        tile_n = grp * G + idx % G;
-        tile_m = idx / G;
-    }
     const int d = p.dil;
     // tile_m -> (image, phase_y, phase_x, tile_y, tile_x)
     const int per_phase = g.tiles_y * g.tiles_x;
@@ -309,22 +302,11 @@ conv_fullk_kernel(const ConvArgs p, const FullkArgs g) {
                 if (st + 1 < NSUB) read_a(fa[(st + 1) & 1], st + 1);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    if (p.dbg == 21) {   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): operands fetched, no MFMA
-                        acc[a][0][0] += vt_u2f(w0.x ^ fa[st & 1][a].x);
-                        acc[a][1][0] += vt_u2f(w1.x ^ fa[st & 1][a].x);
-                    } else {
-                        Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
-                        Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
-                    }
+                    Mma<T>::run(acc[a][0], w0, fa[st & 1][a]);
+                    Mma<T>::run(acc[a][1], w1, fa[st & 1][a]);
                 }
             }
         }
-    }
-    if (p.dbg == 22) {   // ablation: no cross-wave sum, no epilogue
-        float sacc = 0.f;
-        for (int a = 0; a < 4; ++a) sacc += acc[a][0][0] + acc[a][1][0] + acc[a][0][3] + acc[a][1][2];
-        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
-        return;
     }
     // ---- sum the 8 partial tiles through LDS (each wave parks its tile in its own patch region) ----
     // scratch image: row = tile pixel (128 B = 32 fp32 channels), 16-byte slot s at s ^ (pixel & 7)
@@ -504,14 +486,6 @@ int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
-    static const int depth = [] {   // VT_FULLK_DEPTH: A/B of the weight ring depth (6 or 9 sub-steps)
-        const char* e = getenv("VT_FULLK_DEPTH");
-        return e ? atoi(e) : FK_DEPTH_DEFAULT;
-    }();
-    static const int aux = [] {     // VT_FULLK_AUX: A/B of the weight loads' cache policy (1 nt, 2 sc1, 3 sc0 sc1)
-        const char* e = getenv("VT_FULLK_AUX");
-        return e ? atoi(e) : 0;
-    }();
     if constexpr (sizeof(T) == 4 && !is_x3<T>::value) {
         if (a.x3) {   // f32x3 instance (conv_igemm.hip, "f32x3")
             auto k = conv_fullk_kernel<f32x3_t, FK_DEPTH_DEFAULT>;
@@ -519,21 +493,7 @@ int launch_fullk(const ConvArgs& a, const FullkArgs& g, vt_stream stream) {
             return vt_check_launch("vt_conv2d(whole-K, f32x3)");
         }
     }
-    if (depth == 9) {
-        auto k = conv_fullk_kernel<T, 9>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    } else if (aux == 1) {
-        auto k = conv_fullk_kernel<T, 6, 1>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    } else if (aux == 2) {
-        auto k = conv_fullk_kernel<T, 6, 2>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    } else if (aux == 3) {
-        auto k = conv_fullk_kernel<T, 6, 3>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    } else {
-        auto k = conv_fullk_kernel<T, 6>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    }
+    auto k = conv_fullk_kernel<T, FK_DEPTH_DEFAULT>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
     return vt_check_launch("vt_conv2d(fullk)");
 }

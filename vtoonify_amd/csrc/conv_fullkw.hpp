@@ -585,49 +585,23 @@ int launch_fullkw(const ConvArgs& a, FullkwArgs g, int group, vt_stream stream) 
         return VT_ERR_ARG;
     }
     // XCD grid: minimise the bytes the 8 L2s fetch between them, weights x xm + activations (with halo) x xn, over the
-    // splits that divide the grid.  VT_FULLKW_XM forces xm (1, 2, 4, 8; 0 = decode_block's order) for A/B runs.
+    // splits that divide the grid.
     {
         constexpr int ESZ = (int)sizeof(T);
         const double wbytes = (double)a.coutT * a.K * ESZ;
         const double abytes = 1.9 * (double)a.N * a.H * a.W * a.cin * ESZ;
-        const char* fe = getenv("VT_FULLKW_XM");
-        const int forced = fe ? atoi(fe) : -1;
         double best = 1e300;
         g.xm = g.xn = 0;
         for (int xm = 1; xm <= 8; xm *= 2) {
             const int xn = 8 / xm;
             if (args.tiles_m % xm || args.tiles_n % xn) continue;
-            if (forced >= 0 && xm != forced) continue;
             // a sub-grid whose operands do not fit the L2 streams them: price that like a miss per reader
             const bool fits = wbytes / xn + abytes / xm <= 3.5e6;
             const double cost = (wbytes * xm + abytes * xn) * (fits ? 1.0 : 4.0);
             if (cost < best) best = cost, g.xm = xm, g.xn = xn;
         }
-        if (forced == 0) g.xm = g.xn = 0;
     }
-    static const bool safe = [] {   // VT_FULLKW_SAFE=1: every counted wait becomes vmcnt(0) (bisection aid)
-        const char* e = getenv("VT_FULLKW_SAFE");
-        return e && e[0] == '1';
-    }();
-    const char* ae = getenv("VT_FULLKW_ABLATE");
-    const int abl = ae ? atoi(ae) : 0;
-#define VT_FKW_ABL(A_)                                                                  \
-    if (abl == A_) {                                                                   \
-        auto k = conv_fullkw_kernel<T, 0, A_>;                                         \
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);       \
-        return vt_check_launch("vt_conv2d(fullkw ablation)");                          \
-    }
-    if (sizeof(T) == 2 && abl) {
-        VT_FKW_ABL(31) VT_FKW_ABL(32) VT_FKW_ABL(33) VT_FKW_ABL(35) VT_FKW_ABL(36) VT_FKW_ABL(37) VT_FKW_ABL(38)
-        VT_FKW_ABL(41) VT_FKW_ABL(42) VT_FKW_ABL(43) VT_FKW_ABL(44) VT_FKW_ABL(45) VT_FKW_ABL(46)
-    }
-#undef VT_FKW_ABL
-    if (safe) {
-        auto k = conv_fullkw_kernel<T, 1>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    } else {
-        auto k = conv_fullkw_kernel<T, 0>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
-    }
+    auto k = conv_fullkw_kernel<T, 0>;
+    VT_LAUNCH(k, dim3((unsigned)blocks), dim3(FK_NW * 64), stream, args, g);
     return vt_check_launch("vt_conv2d(fullkw)");
 }

@@ -87,7 +87,6 @@ struct ConvArgs {
     const float* up_fir;        // conv_transpose2d(stride 2) + blur form (conv_upblur.hpp) or NULL
     int rgb_only;               // vt_conv_desc.rgb_only: the C-channel output is not stored (fused ToRGB only)
     int in_absdiff;             // vt_conv_desc.in_absdiff: input = cat[src0, |src0 - src1|] (thin kernel)
-    int dbg;            // VT_RGB_ABLATE (tools/conv_bench.py only): 1 no rgb stores, 2 no skip loads, 3 no shuffles
     int x3;             // vt_conv_desc.dtype == VT_F32X3: fp32 tensors, products as three bf16 MFMAs where the instance exists
 };
 
@@ -521,7 +520,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         }
         // fall through to the fused epilogue below
     }
-    if (p.dbg == 7 && acc[0][0][0] != 123.456f) return;   // ablation (tools/conv_bench.py): no epilogue
     const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
     // Fused ToRGB (model/stylegan/model.py:383-392): when this tile holds ALL output channels of its
     // pixels, the 1x1 modulated conv C -> 3 that follows a same-resolution StyledConv is three dot
@@ -858,7 +856,7 @@ struct GldsArgs {
     uint32_t bias0, bias1;          // bytes the source bases are moved back by ((pad*W+pad) pixels)
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int DBG = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NST>
 __global__ void __launch_bounds__(256)
 conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
@@ -925,14 +923,13 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     // K-step state (all wave-uniform); `tap`/`kc` describe the NEXT step to be issued
     const int nk_all = p.K / BK;
     const int kt0 = split * p.kps;
-    const int kt1 = (DBG == 3 || DBG == 5) ? kt0 + 1 : (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;  // DBG 3: one K-step
+    const int kt1 = (kt0 + p.kps < nk_all) ? kt0 + p.kps : nk_all;
     int tap = (kt0 * BK) / p.cin;
     int kc = kt0 * BK - tap * p.cin;   // channel offset inside the concatenated input
     int seg_tap = -1, seg_src = -1;
     uint32_t soff_a = 0;               // byte offset of (tap, first channel of the source)
 
     auto issue = [&](int kt, int buf) {
-        if (DBG == 2) return;  // ablation: no global->LDS traffic
         const int src = (kc >= p.c0) ? 1 : 0;
         if (tap != seg_tap || src != seg_src) {   // uniform: new tap or new source
             seg_tap = tap;
@@ -1010,10 +1007,7 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    if (DBG == 1) acc[a][b][0] += vt_u2f(fa[a].x ^ fb[b].x);  // ablation: LDS reads kept, no MFMA
-                    else Mma<T>::run(acc[a][b], fb[b], fa[a]);
-                }
+                for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], fb[b], fa[a]);
         }
         }
         // step kt+1 must have landed (in every wave) before anyone reads it; step kt's buffer may
@@ -1024,13 +1018,6 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
         nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
     }
     __syncthreads();
-    if (DBG == 4 || DBG == 5) {  // ablation: no epilogue (4) / one K-step and no epilogue (5)
-        float sacc = 0.f;
-        for (int a = 0; a < TM; ++a)
-            for (int b = 0; b < TN; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-        if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
-        return;
-    }
     conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, LinearRows{m0, p.M}, n0, split, tile_n * p.tiles_m + tile_m);
 }
 
@@ -1366,7 +1353,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             const int im = mm / HoWo;
             o_rgb = (int64_t)im * 3 * HoWo + (mm - im * HoWo);
         }
-        if (rgbf && p.rgb_resid && p.dbg != 2) {
+        if (rgbf && p.rgb_resid) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) rsd[j] = p.rgb_resid[o_rgb + (int64_t)j * HoWo];
         }
@@ -1433,16 +1420,14 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                 for (int j = 0; j < 3; ++j) {
                     float keep_a = hi ? rp[2][j] : rp[0][j], keep_b = hi ? rp[3][j] : rp[1][j];
                     const float send_a = hi ? rp[0][j] : rp[2][j], send_b = hi ? rp[1][j] : rp[3][j];
-                    if (p.dbg != 3) {
-                        keep_a += __shfl_xor(send_a, 32, 64);
-                        keep_b += __shfl_xor(send_b, 32, 64);
-                    }
+                    keep_a += __shfl_xor(send_a, 32, 64);
+                    keep_b += __shfl_xor(send_b, 32, 64);
                     float keep = odd ? keep_b : keep_a;
                     const float send = odd ? keep_a : keep_b;
-                    if (p.dbg != 3) keep += __shfl_xor(send, 16, 64);
+                    keep += __shfl_xor(send, 16, 64);
                     rr[j] = keep;
                 }
-                if (m_rgb >= 0 && (p.dbg != 1 || rr[0] == 123.456f)) {
+                if (m_rgb >= 0) {
                     p.rgb_out[o_rgb] = rr[0] + rb0 + rsd[0];
                     p.rgb_out[o_rgb + HoWo] = rr[1] + rb1 + rsd[1];
                     p.rgb_out[o_rgb + 2 * (int64_t)HoWo] = rr[2] + rb2 + rsd[2];
@@ -1458,7 +1443,6 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #include "conv_fullkw.hpp"
 #include "conv_upblur.hpp"
 #include "conv_thin.hpp"
-#include "conv_c64.hpp"
 #include "conv_patch_pipe.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
@@ -1823,6 +1807,25 @@ static bool patch_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
+// conv_transpose2d(3x3, stride 2, pad 0) by output parity on the pipelined patch tiles (conv_patch_pipe.hpp, UP = 1)
+template <typename T>
+static bool up_eligible(const ConvArgs& a, GldsArgs& g) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BK = 8 * (16 / ESZ);
+    if (a.force_generic || !a.transposed || a.in_scale || a.rgb_w || a.stats_part || a.tile_stats || a.in_tile_stats) return false;
+    if (a.taps != 9 || a.kw != 3 || a.stride != 2 || a.pad != 0 || a.pad_x != 0 || a.dil != 1 || a.phases != 1) return false;
+    if (a.Ho != 2 * a.H + 1 || a.Wo != 2 * a.W + 1 || a.c1 != 0 || a.c0 % BK != 0 || a.coutT % 8 != 0) return false;
+    if (a.out_layout != VT_OUT_NHWC) return false;
+    const int64_t lim = ((int64_t)1 << 31) - 4096;
+    const int64_t n0 = (int64_t)a.N * a.H * a.W * a.ld0 * ESZ, nw = (int64_t)a.coutT * a.K * ESZ;
+    if (n0 >= lim || nw >= lim) return false;
+    g.nrec0 = (uint32_t)n0;
+    g.nrec1 = 0;
+    g.nrecw = (uint32_t)nw;
+    g.bias0 = g.bias1 = 0;
+    return true;
+}
+
 template <typename T>
 static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
     if (sizeof(T) != 2 || a.force_generic || a.transposed || a.in_scale) return false;
@@ -1843,18 +1846,7 @@ static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
 template <typename T>
 static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
-    static const int wg_target = [] {   // EXPERIMENT switch: workgroups a split-K launch aims for (256 = one per CU)
-        const char* e = getenv("VT_SPLITK_WGS");
-        return e && atoi(e) > 0 ? atoi(e) : 256;
-    }();
-    static const bool small_lds = [] {
-        const char* e = getenv("VT_SMALL_LDS");
-        return e && e[0] == '1';
-    }();
-    static const int fullk = [] {
-        const char* e = getenv("VT_FULLK");
-        return e ? atoi(e) : 0;
-    }();
+    constexpr int wg_target = 256;   // workgroups a split-K launch aims for: one per CU
     TilePlan t;
     t.kind = 0;
     t.bm = t.bn = 0;
@@ -1873,12 +1865,19 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     const int hp = (hint / 100000000) % 10;
     const int hs = (hint / 1000000) % 100, hbm = (hint / 1000) % 1000, hbn = hint % 1000;
     {
+        // conv_transpose2d(3x3, stride 2) with wide channels: by output parity on the pipelined patch tiles
+        // (256 quads x 64 channels x 4 parity classes per workgroup); anything else transposed: the gather form below
+        GldsArgs gu;
+        if (hp != 2 && hbm == 0 && hs == 0 && a.coutT >= 64 && a.cin >= 128 && up_eligible<T>(a, gu)) {
+            t.kind = 1;
+            t.bm = 256, t.bn = 64;
+            t.splitk = 1;
+            return t;
+        }
+    }
+    {
         // thin outputs (cout <= 3, planar): one launch, K over the wavefronts of a workgroup, no slabs
-        static const bool thin_on = [] {   // VT_THIN_KERNEL=0: the tile kernels + split-K instead (A/B)
-            const char* e = getenv("VT_THIN_KERNEL");
-            return !(e && e[0] == '0');
-        }();
-        if ((hp == 6 || (thin_on && hp == 0 && hbm == 0 && hs == 0)) && thin_eligible<T>(a)) {
+        if ((hp == 6 || (hp == 0 && hbm == 0 && hs == 0)) && thin_eligible<T>(a)) {
             t.kind = 6;
             t.bm = TH_TW * TH_TW;
             t.bn = a.taps * a.coutT > 16 ? 32 : 16;
@@ -1905,33 +1904,13 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         return t;
     }
     {
-        static const bool c64_on = [] {   // VT_C64_KERNEL=0: the patch-resident tile kernel instead (A/B)
-            const char* e = getenv("VT_C64_KERNEL");
-            return !(e && e[0] == '0');
-        }();
-        if (c64_on && hp != 2 && hbm == 0 && c64_eligible<T>(a, g)) {   // the 512^2 level: the same, 64 channels
-            t.kind = 7;
-            t.bm = 256;
-            t.bn = 64;
-            t.splitk = 1;
-            return t;
-        }
-    }
-    {
         // whole-K kernel (conv_fullk.hpp): the layers the heuristics below would cut along K into fp32 slabs --
         // few pixels per image, wide channels.  Per-image geometry only (batch-invariant like every plan).
-        static const int fk_mode = [] {   // VT_FULLK_KERNEL=0 disables it (A/B), 2 = also where no split would happen
-            const char* e = getenv("VT_FULLK_KERNEL");
-            return e ? atoi(e) : 1;
-        }();
         FullkArgs fg;
         const bool hinted = hp == 4;
-        if (hp != 2 && (hbm == 0 || hinted) && (fk_mode > 0 || hinted) && fullk_eligible<T>(a, a.wstream, fg)) {
+        if (hp != 2 && (hbm == 0 || hinted) && fullk_eligible<T>(a, a.wstream, fg)) {
             const int64_t wgs = (int64_t)a.dil * a.dil * fg.tiles_y * fg.tiles_x * vt_cdiv(a.coutT, FK_BN);   // per image
-            static const int fk_max_wgs = [] {   // VT_FULLK_MAX_WGS: largest per-image grid the heuristic gives it
-                const char* e = getenv("VT_FULLK_MAX_WGS");
-                return e && atoi(e) > 0 ? atoi(e) : 1024;
-            }();
+            constexpr int fk_max_wgs = 1024;   // largest per-image grid the heuristic gives the whole-K kernel
             // A batch that fills the GPU with 256-pixel x 128-channel patch tiles (one 8-wave workgroup per CU, no K split) is
             // better served by them: 512 -> 512 @64^2 111 -> 82 us, 1024 -> 512 @64^2 250 -> 161 us at 4 frames
             // (profiles/r03_batch_tiles.txt).  The patch kernel sums K in another order than the whole-K kernels, so a frame
@@ -1961,7 +1940,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
                 t.splitk = 1;
                 return t;
             }
-            if (hinted || fk_mode >= 2 || (a.coutT >= 128 && wgs <= fk_max_wgs)) {
+            if (hinted || (a.coutT >= 128 && wgs <= fk_max_wgs)) {
                 t.kind = 4;
                 t.bm = FK_TH * FK_TW;
                 t.bn = FK_BN;
@@ -2003,10 +1982,6 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         const int units_p = a.cin / BK;
         if (a.dil == 1 && a.coutT <= 16) {
             t.bm = 128, t.bn = 16;
-        } else if (small_lds && a.dil == 1 && a.coutT >= 64 && ptiles(16, 64) >= 192) {
-            // EXPERIMENT (VT_SMALL_LDS=1): 72 KB instances only, so that two workgroups -- of this launch or
-            // of another frame in flight -- share a CU (the 256-pixel tiles take 144 KB)
-            t.bm = 128, t.bn = 64;
         } else if (a.dil == 1 && a.coutT >= 128 && ptiles(16, 128) >= 192) {
             t.bm = 256, t.bn = 128;
         } else if (a.dil == 1 && a.coutT >= 128 && (int64_t)a.N * ptiles(16, 128) >= 256 &&
@@ -2021,11 +1996,6 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             t.splitk = 1;
         } else if (a.dil == 1 && a.coutT == 64 && ptiles(16, 64) >= 192) {
             t.bm = 256, t.bn = 64;
-        } else if (fullk > 0 && a.coutT >= 128 && a.coutT % 64 == 0 && ptiles(8, 128) < 192 && ptiles(4, 64) >= 96) {
-            // EXPERIMENT (VT_FULLK=n): 64-pixel x 64-channel tiles that keep (1/n of) the whole K range in
-            // one workgroup -- no (n = 1) or n-slice fp32 slabs instead of one slab per channel chunk
-            t.bm = 64, t.bn = 64;
-            t.splitk = fullk < units_p ? fullk : units_p;
         } else if (a.coutT >= 128 && ptiles(8, 128) < 192 &&
                    (a.dil == 1 || ptiles(8, 128) * units_p <= 1024)) {
             t.bm = 128, t.bn = 128;
@@ -2128,13 +2098,13 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int PIN = 0, int ABL = 0>
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0>
 int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
     args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;   // matches PERM of the kernel instance
     args.tiles_n = vt_cdiv(a.coutT, BN);
-    args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
+    args.tiles_m = UP ? a.N * vt_cdiv(a.H + 1, TH) * vt_cdiv(a.W + 1, 16) : a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
     const int units = a.cin / BK;
     args.kps = vt_cdiv(units, args.splitk);
     args.splitk = vt_cdiv(units, args.kps);
@@ -2145,7 +2115,7 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         return VT_ERR_ARG;
     }
     if (args.phase != 2) {
-        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, PIN, ABL>;
+        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
     }
     int rc = vt_check_launch("vt_conv2d(patch, pipelined)");
@@ -2208,15 +2178,8 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         // 768 workgroups, 81 vs 85 us)
         const int64_t wgs_all = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28) * vt_cdiv(a.coutT, t.bn);
         const bool db = de ? chunks >= atoi(de) : (chunks >= 4 && (t.bn == 16 || wgs_all <= 768));
-        // single-chunk layers with many tiles per CU (the 1024^2 level): persistent workgroups, resident weights.
-        // VT_UPBLUR_PERSIST = minimum number of workgroups for the persistent form (0 = never; tests use 1)
-        const char* pe = getenv("VT_UPBLUR_PERSIST");
-        const int64_t persist_min = pe ? atoll(pe) : 0;   // measured slower than two plain workgroups per CU (54 vs 70 us)
-        const int64_t tiles = (int64_t)a.N * vt_cdiv(2 * a.H, 20) * vt_cdiv(2 * a.W, 28);
-        // single-stage forms capped at 256 registers (2 workgroups per CU, a few cold values spilled): 40 vs 51 us
-        // and 54 vs 77 us on the 256^2 / 512^2-pixel levels; VT_UPBLUR_LB2=0 for the uncapped build
-        const char* le = getenv("VT_UPBLUR_LB2");
-        const bool lb2 = !(le && le[0] == '0');
+        // (single-stage 32-channel forms are capped at 256 registers -- 2 workgroups per CU, a few cold values spilled: 40 vs
+        // 51 us and 54 vs 77 us on the 256^2 / 512^2-pixel levels)
         if constexpr (sizeof(T) == 2) {
             // single-chunk layers (the 1024^2 level) with >= 4 tiles per CU: persistent 8-wave workgroups on 16 x 16-quad tiles
             // -- the 36 KB of weights stay in LDS instead of being re-fetched by every tile (more than the tile's 28 KB
@@ -2228,8 +2191,6 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             const bool on = p8 ? p8[0] == '1' : tiles8 >= 1024;
             if (on && t.bn == 32 && chunks == 1) return launch_upblur<T, 32, 16, 0, 1, 0, 8>(a, stream);
         }
-        if (t.bn == 32 && chunks == 1 && persist_min > 0 && tiles * vt_cdiv(a.coutT, 32) >= persist_min)
-            return launch_upblur<T, 32, 12, 0, 1, 0>(a, stream);
         {
             // tall tiles (24 x 16 quads, 8 waves, one workgroup per CU) where the layer is bound by L2 -> LDS bytes -- four or
             // more channel chunks -- and still gives every CU ~2 workgroups: 125 -> 100 us (512 -> 256) and 132 -> 119 us
@@ -2246,7 +2207,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         }
         if (t.bn == 16) return db ? launch_upblur<T, 16, 12, 1, 0, 0>(a, stream) : launch_upblur<T, 16, 12, 0, 0, 0>(a, stream);
         if (db) return launch_upblur<T, 32, 12, 1, 0, 0>(a, stream);
-        return lb2 ? launch_upblur<T, 32, 12, 0, 0, 1>(a, stream) : launch_upblur<T, 32, 12, 0, 0, 0>(a, stream);
+        return launch_upblur<T, 32, 12, 0, 0, 1>(a, stream);
     }
     if ((a.tile_stats || a.in_tile_stats) && t.kind != 4 && t.kind != 8) {
         vt_set_error("vt_conv2d: tile_stats / in_tile_stats need the whole-K kernel (plan kind %d)", t.kind);
@@ -2277,14 +2238,6 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         }
         return launch_fullk<T>(a, fg, stream);
     }
-    if (t.kind == 7) {
-        GldsArgs g;
-        if (!c64_eligible<T>(a, g)) {
-            vt_set_error("vt_conv2d: c64 kernel requested for an ineligible convolution");
-            return VT_ERR_UNSUPPORTED;
-        }
-        return launch_c64<T>(a, g, stream);
-    }
     if (t.kind == 3) {
         GldsArgs g;
         if (!c32_eligible<T>(a, g)) {
@@ -2292,6 +2245,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             return VT_ERR_UNSUPPORTED;
         }
         return launch_c32<T>(a, g, stream);
+    }
+    if (t.kind == 1 && a.transposed) {
+        GldsArgs g;
+        if (!up_eligible<T>(a, g)) {
+            vt_set_error("vt_conv2d: transposed patch plan requested for an ineligible convolution");
+            return VT_ERR_UNSUPPORTED;
+        }
+        return launch_patchp<T, 16, 64, 4, 2, 8, 1>(a, g, stream);
     }
     if (t.kind == 1) {
         GldsArgs g;
@@ -2309,39 +2270,17 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // VT_PATCH_PIPE=0: the per-tap form below (A/B; read per call: tests flip it)
             const char* e = getenv("VT_PATCH_PIPE");
             const bool pipe = !(e && e[0] == '0') && !a.x3;   // (f32x3 runs the per-tap form: its instances live there)
-            if constexpr (sizeof(T) == 2) {   // A/B + ablations (tools/conv_bench.py; removed once measured)
-                const bool big = pipe && e && a.dil == 1 && t.bm == 256 && t.bn == 128;
-                if (big && e[0] == '2') return launch_patchp<T, 16, 128, 4, 2, 4, 1>(a, g, stream);
-                if (big && e[0] == '3') return launch_patchp<T, 16, 128, 4, 2, 4, 2>(a, g, stream);
-                if (big && e[0] == '4') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 4>(a, g, stream);
-                if (big && e[0] == '5') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 5>(a, g, stream);
-                if (big && e[0] == '6') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 6>(a, g, stream);
-                if (big && e[0] == '9') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 7>(a, g, stream);
-                if (big && e[0] == 'a') return launch_patchp<T, 16, 128, 4, 2, 4, 0, 8>(a, g, stream);
-            }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
-            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2>(a, g, stream);
-            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) {
-                if (e && e[0] == '7') return launch_patchp<T, 16, 32, 8, 1, 4>(a, g, stream);
-                if (e && e[0] == '8') return launch_patchp<T, 16, 32, 8, 1, 6>(a, g, stream);
-                return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
-            }
+            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);
+            if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
         }
         VT_PATCH(16, 128, 4, 2, 1, 3, 2, true)
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)
         VT_PATCH(8, 64, 2, 2, 1, 3, 2, true)
         VT_PATCH(8, 16, 4, 1, 1, 3, 2, true)
-        VT_PATCH(4, 64, 2, 2, 1, 4, 2, true)   // VT_FULLK experiment: whole-K (or few-slice) small tiles
-        VT_PATCH(4, 64, 2, 2, 2, 4, 2, true)
-        VT_PATCH(4, 64, 2, 2, 4, 4, 2, true)
         // one chunk per slice = single patch buffer.  Short ring (71 KB: TWO workgroups per CU, the
         // prologue / epilogue of one overlaps the taps of the other) when the launch runs several
         // rounds of workgroups; deep ring (5 taps in flight) for the latency-bound single round.
-        {
-            const char* e = getenv("VT_PATCH_OCC2");   // EXPERIMENT switch
-            const bool occ2 = e && e[0] == '1';
-            VT_PATCH(8, 128, 2, 2, 1, 3, 1, one_chunk && occ2)
-        }
         VT_PATCH(8, 128, 2, 2, 1, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 2, 6, 1, one_chunk)
         VT_PATCH(8, 128, 2, 2, 4, 6, 1, one_chunk)
@@ -2410,10 +2349,6 @@ static int fill_args(const vt_conv_desc* d, ConvArgs& a) {
     a.rgb_resid = d->rgb_resid;
     a.rgb_out = d->rgb_out;
     a.stats_part = (StatRec*)d->stats_part;
-    {
-        const char* e = getenv("VT_RGB_ABLATE");
-        a.dbg = e ? atoi(e) : 0;
-    }
     a.x3 = d->dtype == VT_F32X3 ? 1 : 0;
     a.alpha_dev = d->alpha_dev;
     a.post_relu = d->post_relu ? 1 : 0;

@@ -9,16 +9,32 @@
 // bubble:
 //   * the weight ring is 4 deep and the barrier at the end of tap s publishes the weights of tap s+2, so tap s+1's
 //     fragments may be read BEFORE the barrier that ends tap s;
-//   * fragments are double-buffered in registers: while the 16 MFMAs of one half-step run, the 8 ds_read_b128 of the
-//     next half-step (the first half of the NEXT tap in the second half of a tap) are in flight -- the interleave is
-//     pinned with sched_group_barrier, one read per MFMA;
-//   * the LDS-DMA for tap s+3 is issued between the two halves, not at the top of the step, and the next chunk's patch
-//     arrives one 1 KB piece per wave per tap (taps 0..PA-1) instead of PA pieces at once;
+//   * fragments are double-buffered in registers: the source reads the 8 fragments of the next half-step (the first half
+//     of the NEXT tap in the second half of a tap) before the 16 MFMAs of the current one.  The interleave is hipcc's:
+//     pinning it with sched_group_barrier (one read per MFMA, or per two) measured 0-5 % slower on every layer
+//     (profiles/r04_patch_pipeline.txt) -- with two waves per SIMD the partner's MFMAs cover a wave's LDS waits, what
+//     counts is that nothing waits right behind the barrier;
+//   * the LDS-DMA for tap s+D is issued between the two halves, not at the top of the step, and the next chunk's patch
+//     arrives a few 1 KB pieces per wave per tap (taps 0..8-D) instead of PA pieces at once;
 //   * the 9 taps are unrolled at compile time: every LDS offset of a fragment read is an immediate, every counted
 //     `s_waitcnt vmcnt` is a constant (no branch ladder in front of the barrier), and loads past the end of the K
 //     range are issued with an out-of-range offset (the buffer unit zero-fills a dead slot) so that every wave
 //     issues the same number of operations in every step.
 // LDS: 2 patch buffers + 4 weight slots = all 160 KB for the 256-pixel x 128-channel tile (one workgroup per CU).
+//
+// UP = 1: conv_transpose2d(3x3, stride 2, pad 0) -- the first half of an up-sampling StyledConv (model/stylegan/model.py:273-
+// 286) -- by OUTPUT PARITY on the same pipeline.  z[2I+a, 2J+b] += W[a][b] x[I, J]: tap (a, b) only reaches output pixels of
+// parity class (a & 1, b & 1), and for the "quad" (I', J') -- the 2 x 2 output pixels (2I'+pa, 2J'+pb) -- it reads input pixel
+// (I' - a/2, J' - b/2).  With the patch origin where the 3x3 conv has it, that is the ordinary tap (ky, kx) = (a == 2 ? 0 : 1,
+// b == 2 ? 0 : 1): the 9 weight taps are 9 GEMM steps over the resident patch, each accumulating into ONE of four
+// accumulator sets.  9 MACs per input pixel (the reference's count), no halo recompute, tiles of TH x 16 quads over the
+// (H+1) x (W+1) quad grid; the four sets leave through the ordinary epilogue with the rows mapped to (2I'+pa, 2J'+pb).
+// This is the transposed convolution of the operator surface (conv2d_gradfix.conv_transpose2d, what the reference's own
+// StyledConv(upsample) calls in eager mode).  Measured as a replacement for conv_upblur_kernel on the deep generator
+// levels of the frame (z to HBM + a streaming blur pass): 80 + 94 + 110 us against 81 + 103 + 119 us for the one-kernel form
+// before the blur pass (23 + 39 + 63 us) -- tiles over the (H+1) x (W+1) quad grid waste 2.1 / 1.5 / 1.25x at 33^2 / 65^2 /
+// 129^2 and 288 / 400 / 648 workgroups quantise badly to 256 CUs: the raw rate is 0.8-0.9 PFLOP/s, the useful one 0.24-0.41.
+// The engine keeps conv_upblur_kernel (profiles/r04_up_by_parity.txt).
 #pragma once
 
 template <int... I, typename F>
@@ -30,7 +46,18 @@ __device__ __forceinline__ void vt_static_for(F&& f) {
     vt_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int PIN = 0, int ABL = 0>
+// UP: tile row -> z pixel (2I'+pa, 2J'+pb) of the (2H+1) x (2W+1) transposed-conv output, or -1.  Parity 0 exists for
+// I' in [0, H], parity 1 for I' in [0, H-1] (same for columns).
+template <int TW>
+struct QuadRows {
+    int img, y0, x0, pa, pb, H, W;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int qi = y0 + row / TW, qj = x0 + row % TW;
+        return (qi <= H - pa && qj <= W - pb) ? (img * (2 * H + 1) + 2 * qi + pa) * (2 * W + 1) + 2 * qj + pb : -1;
+    }
+};
+
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int TW = 16;
@@ -66,7 +93,9 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     int tile_m, tile_n, split;
     decode_block(p, tile_m, tile_n, split);
-    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    // (UP: tiles of quads over (H+1) x (W+1); p.Ho x p.Wo = (2H+1) x (2W+1) is the z image)
+    const int tiles_x = UP ? (p.W + 1 + TW - 1) / TW : (p.Wo + TW - 1) / TW;
+    const int tiles_y = UP ? (p.H + 1 + TH - 1) / TH : (p.Ho + TH - 1) / TH;
     const int img = tile_m / (tiles_x * tiles_y);
     const int trem = tile_m - img * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
@@ -120,11 +149,14 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
             vt_glds16(rw, smem + 2 * A_BYTES + boff + (i * NW + wave) * 1024, live ? woff[i] : GLDS_OOB, so);
     };
 
-    f32x4 acc[TM][TN];
+    constexpr int NCLS = UP ? 4 : 1;   // accumulator sets: output parity classes of the transposed conv
+    f32x4 acc[NCLS][TM][TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[c][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     // per-lane parts of the fragment addresses.  A: patch row pr = rowconst + wm*TM*PW + l15 with rowconst a compile-time
@@ -141,17 +173,11 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
         bfix[sub] = (uint32_t)(2 * A_BYTES + (wn * (TN * 16) + l15) * 128 + (((sub * 4 + q) ^ l7) << 4));
 
     u128 fa[2][TM], fb[2][TN];
-    if constexpr (ABL == 7 || ABL == 8) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) fa[1][a] = u128{1u, 2u, 3u, (uint32_t)lane};
-#pragma unroll
-        for (int b = 0; b < TN; ++b) fb[1][b] = u128{4u, 5u, 6u, (uint32_t)lane};
-    }
     // fragments of (tap TAP, half SUB) from the patch at `aoff` and the weight slot at `boff`, in the order the MFMAs
     // consume them: fa[0], fb[0..TN-1], fa[1..TM-1]
     auto read_frags = [&](auto tapc, auto subc, u128 (&xa)[TM], u128 (&xb)[TN], int aoff, int boff) {
         constexpr int TAP = decltype(tapc)::value, SUB = decltype(subc)::value;
-        constexpr int ky = TAP / 3, kx = TAP - ky * 3;
+        constexpr int ky = UP ? (TAP / 3 == 2 ? 0 : 1) : TAP / 3, kx = UP ? (TAP % 3 == 2 ? 0 : 1) : TAP % 3;
         auto ra = [&](int a) {
             const int rowc = (a + ky) * PW + kx;   // folds: a and TAP are compile-time after unrolling
             xa[a] = ld128(smem + aoff + aswz[rowc & 7][SUB] + rowc * 128);
@@ -162,33 +188,14 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
         for (int a = 1; a < TM; ++a) ra(a);
     };
-    auto mma_all = [&](const u128 (&xa)[TM], const u128 (&xb)[TN]) {
+    auto mma_all = [&](auto tapc, const u128 (&xa)[TM], const u128 (&xb)[TN]) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int cls = UP ? ((TAP / 3) & 1) * 2 + ((TAP % 3) & 1) : 0;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], xb[b], xa[a]);
+            for (int b = 0; b < TN; ++b) Mma<T>::run(acc[cls][a][b], xb[b], xa[a]);
     };
-    // pinned interleave of one half-step: one fragment read of the next half-step per MFMA (per 4 fp32 MFMAs), then
-    // the remaining MFMAs
-    constexpr int MPF = (ESZ == 4) ? 4 : 1;       // machine MFMAs per fragment product
-    // PIN (A/B, tools/conv_bench.py): 0 = hipcc's own order, 1 = one read per MFMA then the rest, 2 = one read per two MFMAs
-    auto pin_half = [&]() {
-        if constexpr (PIN == 1) {
-            vt_static_for<TM + TN>([&](auto) {
-                vt_sched_group<0x100, 1>();
-                vt_sched_group<0x008, MPF>();
-            });
-            if constexpr (TM * TN > TM + TN) vt_sched_group<0x008, (TM * TN - TM - TN) * MPF>();
-        } else if constexpr (PIN == 2) {
-            constexpr int PER = (TM * TN) / (TM + TN) > 0 ? (TM * TN) / (TM + TN) : 1;
-            vt_static_for<TM + TN>([&](auto) {
-                vt_sched_group<0x100, 1>();
-                vt_sched_group<0x008, PER * MPF>();
-            });
-            if constexpr (TM * TN > PER * (TM + TN)) vt_sched_group<0x008, (TM * TN - PER * (TM + TN)) * MPF>();
-        }
-    };
-
     // ---- prologue: patch of the first chunk, weights of taps 0..2; patch + taps 0, 1 landed -------------
 #pragma unroll
     for (int i = 0; i < PA; ++i) issue_a_piece(ch0, 0, i);
@@ -218,36 +225,39 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
             const int boff1 = slot1 * B_BYTES, boff3 = slotd * B_BYTES;
             vt_sched_fence();
             // first half: MFMAs on the fragments read before the barrier; the second half's fragments arrive
-            if constexpr (ABL != 7 && ABL != 8) read_frags(tc, std::integral_constant<int, 1>{}, fa[1], fb[1], aoff, boff);
-            mma_all(fa[0], fb[0]);
-            pin_half();
+            read_frags(tc, std::integral_constant<int, 1>{}, fa[1], fb[1], aoff, boff);
+            mma_all(tc, fa[0], fb[0]);
             // LDS-DMA of this step: weights of tap s+3 into the slot tap s-1 used (every wave is past it: barrier of
             // step s-1), one piece of the next chunk's patch into the other patch buffer
-            if constexpr (ABL != 4 && ABL != 8) {   // ABL (tools/conv_bench.py only, wrong results): 4 no LDS-DMA in the loop, 5 no barrier, 6 no vmcnt wait, 7 no fragment reads, 8 = 4 + 7
-                issue_b(chunk + c3, t3, boff3);
-                vt_static_for<P1 - P0>([&](auto ic) { issue_a_piece(chunk + 1, aoff ^ A_BYTES, P0 + decltype(ic)::value); });
-                if constexpr (PIN != 0) vt_sched_group<0x020, LB + P1 - P0>();
-            }
+            issue_b(chunk + c3, t3, boff3);
+            vt_static_for<P1 - P0>([&](auto ic) { issue_a_piece(chunk + 1, aoff ^ A_BYTES, P0 + decltype(ic)::value); });
             // second half: MFMAs on the second half's fragments; the first half of tap s+1 arrives (its weights were
             // published by the barrier of step s-1, its patch -- at t == 8 the next chunk's -- by that of tap 7)
-            if constexpr (ABL != 7 && ABL != 8)
-                read_frags(std::integral_constant<int, t1>{}, std::integral_constant<int, 0>{}, fa[0], fb[0],
-                           t == 8 ? (aoff ^ A_BYTES) : aoff, boff1);
-            mma_all(fa[1], fb[1]);
-            pin_half();
+            read_frags(std::integral_constant<int, t1>{}, std::integral_constant<int, 0>{}, fa[0], fb[0],
+                       t == 8 ? (aoff ^ A_BYTES) : aoff, boff1);
+            mma_all(tc, fa[1], fb[1]);
             vt_sched_fence();
             // the weights of tap s+2 (issued in step s+2-D) must have landed: younger are the weights of taps s+3 .. s+D and the
             // patch pieces of the steps since (YOUNG)
-            if constexpr (ABL != 4 && ABL != 6 && ABL != 8) vt_glds_wait_n<(D - 2) * LB + YOUNG>();
+            vt_glds_wait_n<(D - 2) * LB + YOUNG>();
 #ifdef VT_EMU
             vt_lds_barrier();
 #else
-            if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();   // fragment reads in flight cross it: they read slots this barrier does not free
+            __builtin_amdgcn_s_barrier();   // fragment reads in flight cross it: they read slots this barrier does not free
 #endif
             slot = slot1;
         });
         aoff ^= A_BYTES;
     }
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split, tile_n * p.tiles_m + tile_m);
+    if constexpr (UP) {
+        vt_static_for<4>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            conv_epilogue<T, BM, BN, WM, WN>(p, acc[c], smem, QuadRows<TW>{img, y0, x0, c >> 1, c & 1, p.H, p.W}, n0, split,
+                                             tile_n * p.tiles_m + tile_m);
+        });
+    } else {
+        conv_epilogue<T, BM, BN, WM, WN>(p, acc[0], smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split,
+                                         tile_n * p.tiles_m + tile_m);
+    }
 }

@@ -28,7 +28,6 @@
 struct UpblurArgs {
     uint32_t nrec0, nrecw;
     int tiles_y, tiles_x;     // output tiles per image
-    int skew;                 // VT_UPBLUR_SKEW experiment (0 = off)
 };
 
 // NW = wavefronts (3 quad rows each at QY = 3 NW).  4: 12 x 16 quads, two workgroups per CU.  8 (QY = 24): 24 x 16 quads,
@@ -88,13 +87,6 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
     const int per_img = g.tiles_y * g.tiles_x;
     const int n0 = tile_n * CN;
     const int OH = 2 * p.H, OW = 2 * p.W;
-#ifndef VT_EMU
-    // EXPERIMENT (VT_UPBLUR_SKEW=n, tools only): the second wave of workgroups (the second resident workgroup of every
-    // CU) starts n x 2.7 us late, so that the load / MFMA / blur phases of a CU's two workgroups stop coinciding
-    if (g.skew > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(100);
-    }
-#endif
 
     // ---- loader state: patch pixel (py, px) = input pixel (I0 - 2 + py, J0 - 2 + px) --------------------------
     const int lrow = lane >> 3;
@@ -230,7 +222,38 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             if (DB && chunk + 1 < nchunks) issue(chunk + 1, st ^ 1, true);
             const unsigned char* pa = sA(st);
             const unsigned char* pb = sB(st);
-            if (p.dbg == 12) continue;   // ablation (tools/conv_bench.py, VT_RGB_ABLATE): loads only
+            if constexpr (is_x3<T>::value) {
+                // f32x3 (conv_igemm.hip): both 16-byte halves of a lane group's row at once -- chunks q and 4+q of pixels and
+                // weights alike -- split into bf16 head + remainder, three bf16 MFMAs per product
+#pragma unroll
+                for (int sh = 0; sh < 4; ++sh) {
+                    const int di = sh >> 1, dj = sh & 1;
+                    vt_sched_fence();
+                    u128 ah[MF], al[MF];
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) {
+                        const int pr = (wave * MF + m + 1 - di) * PW + (1 - dj) + l15;
+                        x3_split(ld128(pa + pr * 128 + ((q ^ (pr & 7)) << 4)), ld128(pa + pr * 128 + (((4 + q) ^ (pr & 7)) << 4)),
+                                 ah[m], al[m]);
+                    }
+#pragma unroll
+                    for (int ta = 2 * di; ta < (di ? 3 : 2); ++ta)
+#pragma unroll
+                        for (int tb = 2 * dj; tb < (dj ? 3 : 2); ++tb) {
+                            const int tap = ta * 3 + tb, cls = (ta & 1) * 2 + (tb & 1);
+                            u128 bh[TN], bl[TN];
+#pragma unroll
+                            for (int n = 0; n < TN; ++n) {
+                                const unsigned char* row = pb + (tap * CN + n * 16 + l15) * 128;
+                                x3_split(ld128(row + ((q ^ l7) << 4)), ld128(row + (((4 + q) ^ l7) << 4)), bh[n], bl[n]);
+                            }
+#pragma unroll
+                            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                                for (int n = 0; n < TN; ++n) Mma<f32x3_t>::run3(acc[cls][m][n], bh[n], bl[n], ah[m], al[m]);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const int slot = sub * 4 + q;
@@ -262,6 +285,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                         }
                 }
             }
+            }
             if (!DB && chunk + 1 < nchunks) {
                 vt_lds_barrier();   // every wave is done reading the stage
                 issue(chunk + 1, 0, true);
@@ -272,15 +296,6 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             set_patch(tile_m + tile_step);
             issue(0, 0, false);
         }
-        if (p.dbg == 11 || p.dbg == 12) {   // ablation: no z tile, no blur, no store
-            float sacc = 0.f;
-            for (int c = 0; c < 4; ++c)
-                for (int m = 0; m < MF; ++m)
-                    for (int n = 0; n < TN; ++n) sacc += acc[c][m][n][0] + acc[c][m][n][1] + acc[c][m][n][2] + acc[c][m][n][3];
-            if (sacc == 123.456f) ((float*)p.out)[tid] = sacc;
-            goto next_tile;
-        }
-
         // ---- 2. z tile -> LDS.  quad (qy, l15) class (pa, pb) = z pixel (2qy + pa - 1, 2 l15 + pb - 1) of the tile --
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -309,7 +324,6 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             }
         }
         __syncthreads();
-        if (p.dbg == 14) goto next_tile;   // ablation: stop after the z tile
 
         // ---- 3. blur + bias + activation.  out(u, v) = sum_{p,q} z[u + p][v + q] * ky[p] * kx[q] / S in tile coordinates
         // (upfirdn2d pad (1,1): z row u + p - 1 of the image; the tile's z rows start at image row u0 - 1).
@@ -335,15 +349,10 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 #pragma unroll 1
             for (int rr = 0; rr < ROWS + 3; ++rr) {
                 float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
-                if (p.dbg == 16) {   // ablation: no LDS reads in the blur
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) f0[k] = f1[k] = f2[k] = f3[k] = (float)rr;
-                } else {
-                    unpack16<T>(ld128(z0), f0);
-                    unpack16<T>(ld128(z1), f1);
-                    unpack16<T>(ld128(z2), f2);
-                    unpack16<T>(ld128(z3), f3);
-                }
+                unpack16<T>(ld128(z0), f0);
+                unpack16<T>(ld128(z1), f1);
+                unpack16<T>(ld128(z2), f2);
+                unpack16<T>(ld128(z3), f3);
                 z0 += ZLINES * 128; z1 += ZLINES * 128; z2 += ZLINES * 128; z3 += ZLINES * 128;
                 float f[VEC];
 #pragma unroll
@@ -356,7 +365,7 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                     o1[k] = fmaf(h[k], ky[0], bv[k]);
                 }
                 const int u = rr - 3;
-                if (u >= 0 && u0 + r0w + u < OH && colok && !(p.dbg == 13 && f[0] != 123.456f)) {
+                if (u >= 0 && u0 + r0w + u < OH && colok) {
                     if (full) {
                         st128(o, pack16<T>(f));
                     } else {
@@ -367,7 +376,6 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             }
         }
         // (PERSIST: the wait + barrier at the top of the next tile's chunk loop also fences the z tile)
-    next_tile:
         if (!PERSIST) break;
         tile_m += tile_step;
         if (tile_m >= p.tiles_m) break;
@@ -419,9 +427,12 @@ int launch_upblur(const ConvArgs& a, vt_stream stream) {
         if (per_n > args.tiles_m) per_n = args.tiles_m;
         blocks = (int64_t)per_n * args.tiles_n;
     }
-    {
-        const char* e = getenv("VT_UPBLUR_SKEW");
-        g.skew = e ? atoi(e) : 0;
+    if constexpr (sizeof(T) == 4 && !is_x3<T>::value) {
+        if (a.x3) {   // f32x3 instance of the same tile
+            auto k = conv_upblur_kernel<f32x3_t, CN, QY, DB, PERSIST, LB2, NW>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(NW * 64), stream, args, g);
+            return vt_check_launch("vt_conv2d(upblur, f32x3)");
+        }
     }
     auto k = conv_upblur_kernel<T, CN, QY, DB, PERSIST, LB2, NW>;
     VT_LAUNCH(k, dim3((unsigned)blocks), dim3(NW * 64), stream, args, g);

@@ -54,9 +54,6 @@ class _Plan:
         self.masks: List[torch.Tensor] = []
         self.graphs: dict = {}        # with_style -> torch.cuda.CUDAGraph
         self.convs: list = []         # (ConvDesc, info) of every conv launch
-        self.side = None              # side stream of the style branch (fork_style)
-        self.thin = None              # stream of the thin-op branch (fork_thin)
-        self.thin_busy = False        # thin branch forked and not yet joined (state of one _launch)
 
 
 class VToonifyEngine:
@@ -102,22 +99,9 @@ class VToonifyEngine:
         # VT_GRAPH_FIRST=1 (default): capture the hipGraph on the first call of a shape; 0 = on the second (one-off shapes
         # then never pay a capture)
         self.graph_first = os.environ.get("VT_GRAPH_FIRST", "1") != "0"
-        self.fuse_torgb = os.environ.get("VT_FUSE_TORGB", "1") != "0"   # A/B switch
-        # style path on a second stream / graph branch beside the encoder.  OFF by default: measured on one box
-        # (same call) one frame in flight +1 % (style) / +5 % (style + thin), but three frames in flight -31 % /
-        # -20 % -- forked graphs of several lanes collide on the graph's internal streams.  VT_STYLE_FORK=1 /
-        # VT_THIN_FORK=1 turn them on for a latency-bound single-stream caller.
-        self.fork_style = os.environ.get("VT_STYLE_FORK", "0") != "0"
-        # RGB-skip path (fusion_skip conv, skip up-sampling, encoder ToRGB) on a third stream / branch
-        self.fork_thin = os.environ.get("VT_THIN_FORK", "0") != "0"
-        # Fusion gate (AdaIN affine + mask conv + pack) as ONE launch (vt_fusion_gate): VT_FUSE_GATE=1.  Off by default:
-        # measured 24 + 25 + 18 + 42 us against 21 + 24 + 25 + 36 us for the three launches (same box; frame 875 -> 862):
-        # with 16-64 tiles per level the chain load -> MFMA -> stencil -> pack inside ONE workgroup is longer than
-        # three short kernels that each spread over hundreds of workgroups
-        self.fuse_gate = os.environ.get("VT_FUSE_GATE", "0") != "0"
-        # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel)
-        # instead of the polyphase form (36); VT_UPBLUR=0 restores the latter for A/B runs
-        self.use_upblur = os.environ.get("VT_UPBLUR", "1") != "0"
+        # up-sampling StyledConvs as conv_transpose2d + LDS blur (vt_conv_desc.up_fir, 9 MACs per input pixel); the polyphase
+        # form (36) only when the FIR is not separable (checked in _pack_static)
+        self.use_upblur = True
         # per-layer plan overrides {conv_signature(desc): vt_conv_desc.tile_hint}: lets a measured table
         # (tools/plan_sweep.py) pick tile / split-K / kernel family per conv geometry without a rebuild.
         # Like the built-in heuristics the key never contains the batch, so frames stay batch-invariant.
@@ -196,21 +180,19 @@ class VToonifyEngine:
         # fragment-stream images of the static 3x3 weights (vt_conv_weight_stream): lets vt_conv2d run the
         # few-pixel / wide-channel layers (the H/8 x W/8 trunk) on the whole-K kernel -- no split-K slabs
         self._wstream: Dict[int, torch.Tensor] = {}
-        if os.environ.get("VT_FULLK_KERNEL", "1") != "0":
-            unit = 8 * (64 if T == torch.bfloat16 else 32)
-            for key, wt in self.w.items():
-                if wt.ndim == 3 and wt.shape[1] == 9 and wt.shape[2] % unit == 0 and wt.shape[0] % 8 == 0:
-                    st = K.conv_weight_stream(wt)
-                    if st is not None:
-                        self._wstream[wt.data_ptr()] = st
+        unit = 8 * (64 if T == torch.bfloat16 else 32)
+        for key, wt in self.w.items():
+            if wt.ndim == 3 and wt.shape[1] == 9 and wt.shape[2] % unit == 0 and wt.shape[0] % 8 == 0:
+                st = K.conv_weight_stream(wt)
+                if st is not None:
+                    self._wstream[wt.data_ptr()] = st
 
     def _stem32(self, bi: int) -> bool:
-        """Does encoder block `bi` run on 32-channel pixel rows (bf16, a stem of <= 32 inputs -> 32 -> 32k channels)?
-        VT_STEM32=0: the K-step-padded layout of the tile kernels (A/B)."""
+        """Does encoder block `bi` run on 32-channel pixel rows (bf16, a stem of <= 32 inputs -> 32 -> 32k channels)?"""
         sd = self.sd
         w0, w2 = sd[f"encoder.{bi}.0.weight"], sd[f"encoder.{bi}.2.weight"]
         return (bi == 0 and self.dtype == torch.bfloat16 and w0.shape[1] <= 32 and w0.shape[0] == 32 and
-                w2.shape[0] % 32 == 0 and w2.shape[0] <= 256 and os.environ.get("VT_STEM32", "1") != "0")
+                w2.shape[0] % 32 == 0 and w2.shape[0] <= 256)
 
     def _kpad(self, c: int) -> int:
         """Channel count rounded up to the K-step of the LDS loaders (64 bf16 / 32 fp32 channels = 128 bytes)."""
@@ -290,41 +272,15 @@ class VToonifyEngine:
         return {"name": what, "kernel": what, "flops": 0, "bytes": 0}
 
     def _run(self, ops, stream, plan=None):
-        """Issue `ops` in list order.  With a plan (and fork_thin on a GPU) the ops tagged info["branch"] = 1 --
-        the thin convs and FIR filters of the RGB skip path, which only the NEXT ToRGB needs -- go to the plan's
-        second stream: `thin.wait_stream(main)` at every main -> thin transition (a thin op may read anything
-        issued before it), `main.wait_stream(thin)` before the first main op tagged info["join"] (it reads what
-        the thin branch wrote).  Captured, that is a parallel branch of the hipGraph; the list order stays a
-        valid serial order (time_ops, emulation)."""
-        forked = plan is not None and self.fork_thin and self.device.type == "cuda"
-        cur = torch.cuda.current_stream(self.device) if forked else None
-        prev_thin = False   # branch of the previous op
+        """Issue `ops` in list order on `stream`.  (Graph branches for the style path and the RGB-skip path were measured
+        in round 2 -- one frame in flight +1 % / +5 %, three in flight -31 % / -20 %: forked graphs of several lanes collide
+        on the graph's internal streams -- and removed in round 4; the ops keep their "branch" / "join" tags as
+        documentation of what could run beside the main chain.)"""
         for fn, args, what in ops:
-            st = stream
-            if forked:
-                info = what if isinstance(what, dict) else {}
-                if info.get("branch"):
-                    if plan.thin is None:
-                        plan.thin = torch.cuda.Stream(self.device)
-                    if not prev_thin:   # EVERY main -> thin transition: the thin op may read what main just issued
-                        plan.thin.wait_stream(cur)
-                    plan.thin_busy = True
-                    prev_thin = True
-                    st = C.c_void_p(plan.thin.cuda_stream)
-                else:
-                    prev_thin = False
-                    if plan.thin_busy and info.get("join"):
-                        cur.wait_stream(plan.thin)
-                        plan.thin_busy = False
-            rc = fn(*args, st)
+            rc = fn(*args, stream)
             if rc != 0:
                 raise _lib.VtError(f"{self._info(what)['name']} failed (code {rc}): "
                                    f"{self.lib.vt_last_error().decode()}")
-
-    def _join_thin(self, plan):
-        if plan.thin_busy:
-            torch.cuda.current_stream(self.device).wait_stream(plan.thin)
-            plan.thin_busy = False
 
     # ------------------------------------------------------------------ style path
     def _build_style_ops(self, plan: _Plan, ns: int, has_res: bool):
@@ -517,28 +473,12 @@ class VToonifyEngine:
         feat = cur
         pp = 0
         rk = f"encoder.{self.n_down}"
-        fuse_stats = os.environ.get("VT_FUSE_STATS", "1") != "0"   # A/B switch
-        # AdaIN folded into the whole-K convs (vt_conv_desc.tile_stats / in_tile_stats): the producer emits
-        # per-tile {mean, M2} records with its output, the consumer normalises its input patch in LDS -- no
-        # statistics launch, no normalisation launch, no normalised copy of the tensor (12 AdaINs per frame)
-        fuse_adain = False
-        # VT_ADAIN: "plane" (default) = one vt_instnorm_plane launch per AdaIN (statistics + affine from registers: a 10 us
-        # latency chain on a quarter of the CUs, which the other frames in flight fill) between plain convs; "fused" = round 2's tile records + in-LDS rewrite inside the whole-K convs
-        # (no extra launch, but +6.5 us in the producer and +17 us in the consumer of conv_fullkw_kernel, which owns every CU
-        # it runs on: profiles/r03_adain_ab.txt); anything else = the chunk-record path below.
-        adain_mode = os.environ.get("VT_ADAIN", "plane")
-        plane_adain = self.dual and has_res and adain_mode == "plane" and hw <= 4096
-        if self.dual and has_res and not plane_adain and adain_mode in ("plane", "fused") and \
-                os.environ.get("VT_FUSE_ADAIN", "1") != "0":
-            kinds = [self._conv_kind(src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
-                                     weight=self.w[f"res.{r}.conv"], cout=cf, kh=3, kw=3, pad=_DIL[r], dil=_DIL[r],
-                                     out=tmp, ld_out=cf) for r in range(1, 7)]
-            kinds.append(self._conv_kind(src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
-                                         weight=self.w[f"{rk}.0.conv2"], cout=cf, kh=3, kw=3, pad=1, out=tmp, ld_out=cf))
-            fuse_adain = all(k in (4, 8) for k in kinds)
-        if fuse_adain:
-            nb = max(K.conv_tile_stats_bytes(B, h, w, dd, cf) for dd in (1, 2, 4))
-            ts = [self._buf(plan, f"tile_stats{i}", (nb // 4,), f32) for i in range(2)]
+        # AdaIN of the trunk (dualstylegan.py:6-21,38-45): one vt_instnorm_plane launch per AdaIN for planes of at most 4096
+        # pixels (statistics + affine from registers: a 10 us latency chain on a quarter of the CUs, which the other frames in
+        # flight fill) between plain convs -- folding it into the whole-K convs (tile records + in-LDS rewrite, round 2) cost
+        # +6.5 us in the producer and +17 us in the consumer of a kernel that owns every CU it runs on
+        # (profiles/r03_adain_ab.txt).  Larger planes: chunk records from the producing conv's reduce pass + one apply pass.
+        plane_adain = self.dual and has_res and hw <= 4096
         for ii in range(6):
             self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
                           weight=self.w[f"{rk}.{ii}.conv"], cout=cf, kh=3, kw=3, pad=1,
@@ -548,9 +488,7 @@ class VToonifyEngine:
                           weight=self.w[f"{rk}.{ii}.conv2"], cout=cf, kh=3, kw=3, pad=1,
                           bias=sd[f"{rk}.{ii}.conv2.bias"], act=ACT_LRELU, alpha=1 / SQRT2, beta=1 / SQRT2,
                           resid=feat, ld_res=cf, out=nxt, ld_out=cf,
-                          tile_stats=ts[0] if fuse_adain else None,
-                          stats_part=ws if (self.dual and has_res and hw <= 16384 and fuse_stats and not fuse_adain
-                                            and not plane_adain) else None)
+                          stats_part=ws if (self.dual and has_res and hw <= 16384 and not plane_adain) else None)
             feat = nxt
             if plane_adain:
                 r = ii + 1
@@ -576,23 +514,6 @@ class VToonifyEngine:
                               bias=sd[f"res.{r}.conv2.1.bias"], act=ACT_LRELU, gain=SQRT2, alpha_dev=ds, beta=1.0,
                               resid=feat, ld_res=cf, out=nxt, ld_out=cf)
                 feat = nxt
-            elif self.dual and has_res and fuse_adain:
-                r = ii + 1
-                dil = _DIL[r]
-                gb1, gb2 = plan.bufs[f"gb.res.{r}.norm"], plan.bufs[f"gb.res.{r}.norm2"]
-                ldg = 0 if ns == 1 else gb1.shape[1]
-                # AdaResBlock (dualstylegan.py:38-45): conv(AdaIN(feat)) -> conv2(AdaIN(.)) * d_s + feat
-                self._op_conv(ops, plan, src0=feat, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
-                              weight=self.w[f"res.{r}.conv"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
-                              bias=sd[f"res.{r}.conv.1.bias"], act=ACT_LRELU, gain=SQRT2, out=tmp, ld_out=cf,
-                              in_tile_stats=ts[0], in_stats_dil=1, in_gb=gb1, in_ld_gb=ldg, tile_stats=ts[1])
-                nxt = ping[pp]; pp ^= 1
-                self._op_conv(ops, plan, src0=tmp, c0=cf, ld0=cf, n=B, h=h, w=w, out_h=h, out_w=w,
-                              weight=self.w[f"res.{r}.conv2"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
-                              bias=sd[f"res.{r}.conv2.1.bias"], act=ACT_LRELU, gain=SQRT2, alpha_dev=ds, beta=1.0,
-                              resid=feat, ld_res=cf, out=nxt, ld_out=cf,
-                              in_tile_stats=ts[1], in_stats_dil=dil, in_gb=gb2, in_ld_gb=ldg)
-                feat = nxt
             elif self.dual and has_res:
                 r = ii + 1
                 dil = _DIL[r]
@@ -604,7 +525,7 @@ class VToonifyEngine:
                     # affine (in_scale/in_shift of vt_conv2d) costs more in the MFMA loop than this
                     if hw <= 16384:   # fused finalize+apply for small planes; the chunk records come
                         # from the conv that produced `src` (its split-K reduce pass emits them)
-                        ops.append((lib.vt_instnorm_apply_stats if fuse_stats else lib.vt_instnorm_apply,
+                        ops.append((lib.vt_instnorm_apply_stats,
                                     (C.c_void_p(nrm_res.data_ptr()), cf, C.c_void_p(src.data_ptr()), cf, B, hw, cf,
                                      C.c_void_p(gb.data_ptr()), 0 if ns == 1 else gb.shape[1],
                                      C.c_void_p(ws.data_ptr()), dt),
@@ -629,7 +550,7 @@ class VToonifyEngine:
                                       weight=self.w[f"res.{r}.{cn}"], cout=cf, kh=3, kw=3, pad=dil, dil=dil,
                                       bias=sd[f"res.{r}.{cn}.1.bias"],
                                       act=ACT_LRELU, gain=SQRT2, out=dst, ld_out=cf,
-                                      stats_part=ws if (hw <= 16384 and fuse_stats) else None)
+                                      stats_part=ws if hw <= 16384 else None)
                     else:
                         nxt = ping[pp]; pp ^= 1
                         # out * d_s + skip  (d_s read from device memory: graph-replay safe)
@@ -662,71 +583,42 @@ class VToonifyEngine:
                     sh = self._buf(plan, f"fsh{lvl}", (B, 2 * co), f32)
                     ws = self._buf(plan, f"fws{lvl}", (max(K.instnorm_ws_bytes(B, hw, 2 * co), 16),), torch.uint8)
                     gb = plan.bufs[f"gb.fus.{lvl}"]
-                    # VT_FUSION_PLANE=1: statistics + affine of cat[f_G, |f_G - f_E|] of the small planes in ONE register-resident
-                    # launch (vt_instnorm_plane) instead of partial + finalize + apply -- 4 launches fewer per frame, measured
-                    # 0.6 % SLOWER at 4 frames (1110 vs 1117 frames/s same box, profiles/r03_adain_ab.txt: unlike the trunk's
-                    # AdaIN it replaces streaming kernels, not work inside a CU-owning conv), so it stays opt-in
-                    fus_plane = (not self.fuse_gate and hw <= 4096 and os.environ.get("VT_FUSION_PLANE", "0") == "1")
-                    if fus_plane:
-                        nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                        ops.append((lib.vt_instnorm_plane,
-                                    (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
-                                     C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
-                                     0 if ns == 1 else gb.shape[1], dt),
-                                    {"name": "adain_cat", "kernel": "instnorm_plane", "flops": 0,
-                                     "bytes": 4 * B * hw * co * self.esz}))
-                    else:
-                        ops.append((lib.vt_instnorm_stats,
-                                    (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
-                                     C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
-                                     0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
-                                    {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
-                                     "bytes": 2 * B * hw * co * self.esz}))
+                    ops.append((lib.vt_instnorm_stats,
+                                (C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_void_p(out.data_ptr()), co,
+                                 C.c_void_p(f_e.data_ptr()), co, B, hw, co, C.c_void_p(gb.data_ptr()),
+                                 0 if ns == 1 else gb.shape[1], C.c_void_p(ws.data_ptr()), dt),
+                                {"name": "instnorm", "kernel": "instnorm_stats", "flops": 0,
+                                 "bytes": 2 * B * hw * co * self.esz}))
                     mask = self._buf(plan, f"mask{lvl}", (B, 1, h, w), f32)
-                    if self.fuse_gate:
-                        # AdaIN affine + |f_G - f_E| + mask conv + [skip | f_E * m] pack in ONE launch (vt_fusion_gate)
-                        ops.append((lib.vt_fusion_gate,
-                                    (C.c_void_p(mask.data_ptr()), C.c_void_p(fem.data_ptr()), co + FEM_HDR,
-                                     C.c_void_p(out.data_ptr()), co, C.c_void_p(f_e.data_ptr()), co,
-                                     C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()),
-                                     C.c_void_p(self.w[f"fusion_out.{lvl}.conv2"].data_ptr()),
-                                     C.c_void_p(sd[f"fusion_out.{lvl}.conv2.bias"].data_ptr()),
-                                     C.c_void_p(skip.data_ptr()), B, h, w, co, dt),
-                                    {"name": "fusion_gate", "kernel": "fusion_gate", "flops": 2 * B * hw * 2 * co * 9,
-                                     "join": True, "bytes": B * hw * (2 * co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
+                    mask_kw = dict(n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1,
+                                   kh=3, kw=3, pad=1, bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH,
+                                   out=mask, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32)
+                    # the mask conv forms cat[f_G, |f_G - f_E|] and applies the AdaIN affine in its loader
+                    # (vt_conv_desc.in_absdiff + in_scale / in_shift: bit-identical to vt_affine_apply -> conv, without
+                    # the launch and the 2C-channel normalised copy) -- not at the H/8 level: 16 tiles per frame cannot hide
+                    # the one-step-in-flight second half of the prologue form's K range (38 us against 7 + 18 for the two
+                    # launches).  VT_GATE_LOADER (test hook): 0 = the two launches everywhere, 2 = the loader form everywhere.
+                    gate_kw = dict(src0=out, c0=co, ld0=co, src1=f_e, c1=co, ld1=co, in_scale=sc, in_shift=sh, in_absdiff=1)
+                    gl = os.environ.get("VT_GATE_LOADER", "1")
+                    in_loader = (gl != "0" and (hw >= 4096 or gl == "2") and self._conv_kind(**gate_kw, **mask_kw) == 6)
+                    if in_loader:
+                        self._op_conv(ops, plan, **gate_kw, **mask_kw)
                     else:
-                        mask_kw = dict(n=B, h=h, w=w, out_h=h, out_w=w, weight=self.w[f"fusion_out.{lvl}.conv2"], cout=1,
-                                       kh=3, kw=3, pad=1, bias=sd[f"fusion_out.{lvl}.conv2.bias"], act=ACT_RELU_TANH,
-                                       out=mask, ld_out=0, out_layout=OUT_NCHW, out_dtype=K.VT_F32)
-                        # the mask conv forms cat[f_G, |f_G - f_E|] and applies the AdaIN affine in its loader
-                        # (vt_conv_desc.in_absdiff + in_scale / in_shift: bit-identical to vt_affine_apply -> conv, without
-                        # the launch and the 2C-channel normalised copy).  VT_GATE_LOADER=0: the two launches (A/B)
-                        gate_kw = dict(src0=out, c0=co, ld0=co, src1=f_e, c1=co, ld1=co, in_scale=sc, in_shift=sh, in_absdiff=1)
-                        # (not at the H/8 level: 16 tiles per frame cannot hide the one-step-in-flight second half of the
-                        # prologue form's K range -- 38 us against 7 + 18 for the two launches)
-                        gl = os.environ.get("VT_GATE_LOADER", "1")   # 0: never, 2: at every level (tests)
-                        in_loader = (not fus_plane and gl != "0" and (hw >= 4096 or gl == "2") and
-                                     self._conv_kind(**gate_kw, **mask_kw) == 6)
-                        if in_loader:
-                            self._op_conv(ops, plan, **gate_kw, **mask_kw)
-                        else:
-                            if not fus_plane:
-                                nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
-                                ops.append((lib.vt_affine_apply,
-                                            (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
-                                             C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()),
-                                             C.c_void_p(sh.data_ptr()), B, hw, co, dt),
-                                            {"name": "affine", "kernel": "affine_apply", "flops": 0,
-                                             "bytes": 4 * B * hw * co * self.esz}))
-                            self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, **mask_kw)
+                        nrm = self._buf(plan, f"nrm{lvl}", (B, h, w, 2 * co))
+                        ops.append((lib.vt_affine_apply,
+                                    (C.c_void_p(nrm.data_ptr()), 2 * co, C.c_void_p(out.data_ptr()), co,
+                                     C.c_void_p(f_e.data_ptr()), co, C.c_void_p(sc.data_ptr()),
+                                     C.c_void_p(sh.data_ptr()), B, hw, co, dt),
+                                    {"name": "affine", "kernel": "affine_apply", "flops": 0,
+                                     "bytes": 4 * B * hw * co * self.esz}))
+                        self._op_conv(ops, plan, src0=nrm, c0=2 * co, ld0=2 * co, **mask_kw)
                     plan.masks.append(mask)
-                if not (self.dual and self.fuse_gate):
-                    ops.append((lib.vt_fusion_pack,
-                                (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
-                                 C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
-                                 B, hw, co, dt),
-                                {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0, "join": True,
-                                 "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
+                ops.append((lib.vt_fusion_pack,
+                            (C.c_void_p(fem.data_ptr()), co + FEM_HDR, C.c_void_p(f_e.data_ptr()), co,
+                             C.c_void_p(mask.data_ptr() if mask is not None else 0), C.c_void_p(skip.data_ptr()),
+                             B, hw, co, dt),
+                            {"name": "fusion_pack", "kernel": "fusion_pack", "flops": 0, "join": True,
+                             "bytes": B * hw * (co * self.esz + (co + FEM_HDR) * self.esz + 16)}))
                 fo = self._buf(plan, f"fout{lvl}", (B, h, w, co))
                 wkey = f"fusion_out.{lvl}.conv" if self.dual else f"fusion_out.{lvl}"
                 self._op_conv(ops, plan, src0=out, c0=co, ld0=co, src1=fem.data_ptr() + FEM_HDR * self.esz, c1=co,
@@ -780,13 +672,10 @@ class VToonifyEngine:
                 probe = self._apply_hint(K.make_conv_desc(dtype=self.dt_conv, **same_kw, **rgb_kw))
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
-                fuse_rgb = self.fuse_torgb and tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
-                if tile // 100000000 == 7 and os.environ.get("VT_RGB_FUSE_C64", "1") == "0":
-                    fuse_rgb = False   # A/B: the 64 -> 64 level's ToRGB as its own (streaming) launch
+                fuse_rgb = tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
                 # the LAST level's activation feeds nothing but its ToRGB: with the fused epilogue on the persistent 32 -> 32
-                # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only).  VT_RGB_ONLY=0: A/B.
-                rgb_only = (fuse_rgb and lvl == 4 and tile // 100000000 == 3 and
-                            os.environ.get("VT_RGB_ONLY", "1") != "0")
+                # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only)
+                rgb_only = fuse_rgb and lvl == 4 and tile // 100000000 == 3
                 self._op_conv(ops, plan, join=fuse_rgb, **same_kw, **(rgb_kw if fuse_rgb else {}),
                               **({"rgb_only": 1} if rgb_only else {}))
                 if not fuse_rgb:
@@ -826,7 +715,7 @@ class VToonifyEngine:
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
             kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
                      3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel", 5: "conv_upblur_kernel",
-                     6: "conv_thin_kernel", 7: "conv3x3_c64_kernel", 8: "conv_fullkw_kernel"}[kind]
+                     6: "conv_thin_kernel", 8: "conv_fullkw_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1 and self.lib.vt_conv2d_splitk_mode(C.byref(d)) == 2:
@@ -1004,27 +893,11 @@ class VToonifyEngine:
         """Issue the plan's kernels on the current stream (eager or under graph capture).  The frame is already in
         plan.bufs["x_nhwc"] (forward() converts the caller's tensor in place, outside the graph)."""
         stream = self._stream()
-        fork = with_style and self.fork_style and self.device.type == "cuda"
-        if fork:
-            # The style path (mapping MLPs, modulation) and the encoder share nothing until the generator: two
-            # branches -- a fork / join of streams when eager, two parallel branches of the hipGraph when
-            # captured.  The side stream first waits for everything already on this one (the previous frame's
-            # generator still reads the buffers the style path rewrites).
-            cur = torch.cuda.current_stream(self.device)
-            if plan.side is None:
-                plan.side = torch.cuda.Stream(self.device)
-            plan.side.wait_stream(cur)
-            with torch.cuda.stream(plan.side):
-                self._run(plan.style_ops, C.c_void_p(plan.side.cuda_stream))
-        elif with_style:
+        if with_style:
             self._run(plan.style_ops, stream)
-        plan.thin_busy = False
         self._run(plan.enc_ops, stream, plan)
-        if fork:
-            cur.wait_stream(plan.side)
         if with_gen:
             self._run(plan.gen_ops, stream, plan)
-        self._join_thin(plan)
 
     def _replay(self, plan: _Plan, with_style: bool):
         """hipGraph replay of the whole frame: ~140 kernel launches become one graph launch

@@ -169,18 +169,25 @@ def _fusion(c):
 class VToonify(nn.Module):
     def __init__(self, in_size=256, out_size=1024, img_channels=3, style_channels=512, num_mlps=8,
                  channel_multiplier=2, num_res_layers=6, backbone="dualstylegan",
-                 compute_dtype: Optional[torch.dtype] = None):
+                 compute_dtype: Optional[torch.dtype] = None, exact_fp32: Optional[bool] = None):
         """compute_dtype: the arithmetic the frame runs in.  None = the environment variable VTOONIFY_AMD_DTYPE
-        ("fp32" | "bf16"), default **fp32** -- the reference's own precision (it is fp32 end to end,
-        model/stylegan/op/upfirdn2d_kernel.cu:311), so `style_transfer.py` on this package computes what it computes on
-        the reference to ~5e-6.  bf16 (3-4x the frames/s; PSNR >= 45 dB against the fp32 path) is an
-        explicit choice: VToonify(..., compute_dtype=torch.bfloat16) or VTOONIFY_AMD_DTYPE=bf16."""
+        ("fp32" | "fp32_exact" | "bf16"), default **fp32** -- the reference's own precision (it is fp32 end to end,
+        model/stylegan/op/upfirdn2d_kernel.cu:311).  In fp32 every tensor, weight and non-conv kernel is fp32; the
+        convolutions' products run on the bf16 matrix cores as three terms each (operands split into bf16 head + remainder
+        in registers, fp32 accumulate: `VToonifyEngine(x3=True)`) -- 2-4e-5 of max|y| against the reference
+        (the stated fp32 bar is 1e-4) at 1.5x the frame rate of the exact-fp32 matrix instructions, which remain one switch
+        away: exact_fp32=True or VTOONIFY_AMD_DTYPE=fp32_exact (~5e-6, the bisection reference).  bf16 (PSNR >= 45 dB against
+        the fp32 path) is an explicit choice: compute_dtype=torch.bfloat16 or VTOONIFY_AMD_DTYPE=bf16
+        (INTEGRATION.md 0)."""
         super().__init__()
+        env = os.environ.get("VTOONIFY_AMD_DTYPE", "fp32").lower()
+        if env not in ("fp32", "float32", "fp32_exact", "bf16", "bfloat16"):
+            raise ValueError(f"VTOONIFY_AMD_DTYPE={env!r}: expected fp32, fp32_exact or bf16")
         if compute_dtype is None:
-            env = os.environ.get("VTOONIFY_AMD_DTYPE", "fp32").lower()
-            if env not in ("fp32", "float32", "bf16", "bfloat16"):
-                raise ValueError(f"VTOONIFY_AMD_DTYPE={env!r}: expected fp32 or bf16")
             compute_dtype = torch.bfloat16 if env.startswith("b") else torch.float32
+        if exact_fp32 is None:
+            exact_fp32 = env == "fp32_exact"
+        self.exact_fp32 = bool(exact_fp32)
         self.backbone = backbone
         self.in_size = in_size
         self.style_channels = style_channels
@@ -228,24 +235,43 @@ class VToonify(nn.Module):
     def invalidate(self):
         """Drop the packed weights (call after editing parameters in place, e.g. through `.data`)."""
         self._engine = None
+        object.__setattr__(self, "_probe_epoch", self._probe_epoch + 1)
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        object.__setattr__(self, "_probe_epoch", self._probe_epoch + 1)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._engine = None
+        object.__setattr__(self, "_probe_epoch", self._probe_epoch + 1)
         return super().load_state_dict(*a, **k)
 
     def _probe(self):
-        """Fingerprint of EVERY parameter and buffer (device, storage address, in-place version counter), ~400 entries
-        per call: a `.to()` or re-assignment of a submodule (`model.generator = ...`), and an in-place edit of any
-        parameter (`p.mul_(...)`, `p.copy_(...)`), all change it and drop the packed weights.  Only edits through
-        `.data` escape the version counters -- those need invalidate()."""
-        h = 0
-        for t in self.state_dict(keep_vars=True).values():
-            h = (h * 1000003 + hash((t.device, t.data_ptr(), t._version))) & 0xFFFFFFFFFFFFFFF
+        """Fingerprint of EVERY parameter and buffer (storage address, in-place version counter): a `.to()`, a re-assignment
+        of a submodule (`model.generator = ...`) and an in-place edit of any parameter (`p.mul_(...)`, `p.copy_(...)`) all
+        change it and drop the packed weights.  Only edits through `.data` escape the version counters -- those need
+        invalidate().  Walking the module tree costs ~2 ms (per call that was most of a 3.5 ms step), so the
+        list of tensors is cached: every call reads the ~400 cached tensors' address / version (0.1 ms); the tree is walked
+        again when this module's own attributes change (__setattr__, _apply, load_state_dict bump an epoch) and on every
+        64th call (a submodule swapped deep inside the tree is noticed within 64 calls; invalidate() is immediate)."""
+        self._probe_calls = getattr(self, "_probe_calls", 0) + 1
+        ts = getattr(self, "_probe_tensors", None)
+        if ts is None or self._probe_epoch_seen != self._probe_epoch or self._probe_calls % 64 == 0:
+            ts = list(self.parameters()) + list(self.buffers())
+            object.__setattr__(self, "_probe_tensors", ts)
+            object.__setattr__(self, "_probe_epoch_seen", self._probe_epoch)
+        h = len(ts)
+        for t in ts:
+            h = (h * 1000003 + t.data_ptr() * 31 + t._version) & 0xFFFFFFFFFFFFFFF
         return h
+
+    _probe_epoch = 0
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, torch.nn.Module)):
+            object.__setattr__(self, "_probe_epoch", self._probe_epoch + 1)
+        super().__setattr__(name, value)
 
     def engine(self) -> VToonifyEngine:
         if self._engine is not None and self._engine_probe != self._probe():
@@ -256,7 +282,8 @@ class VToonify(nn.Module):
             # style_transfer.py:176); the style path is then skipped on the device, bit-identical to recomputing it
             self._engine = VToonifyEngine(self.state_dict(), self.backbone, self.in_size,
                                           self.compute_dtype, dev,
-                                          style_gate=os.environ.get("VT_STYLE_GATE", "1") != "0")
+                                          style_gate=os.environ.get("VT_STYLE_GATE", "1") != "0",
+                                          x3=self.compute_dtype == torch.float32 and not self.exact_fp32)
             self._engine_probe = self._probe()
         return self._engine
 
