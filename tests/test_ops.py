@@ -614,6 +614,7 @@ def test_conv_f32x3(dev):
         (2, 64, 19, 37, 72, 1, 1, 0, False, True),                   # patch, auto plan
         (1, 96, 21, 35, 136, 1, 1, P + 256128, False, True),         # 256 x 128 patch tiles, 3 chunks
         (1, 64, 13, 18, 72, 2, 1, 0, False, True),                   # stride 2: 1-D direct-to-LDS kernel
+        (1, 64, 19, 37, 72, 1, 1, P + 256064, False, True),          # 256 x 64 patch tiles (the per-tap form), 2 chunks
         (2, 256, 9, 11, 136, 1, 1, 0, True, True),                   # whole-K kernel (one round of 8 x 32 channels)
         (1, 256, 12, 10, 40, 1, 2, 4 * P, True, True),               # whole-K, dilated, forced by hint
         (1, 64, 9, 9, 3, 1, 1, 0, False, False),                     # thin outputs: exact fp32

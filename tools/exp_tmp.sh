@@ -1,21 +1,31 @@
-bash tools/ab.sh env VT_C64_KERNEL 1 0 2
 python - <<'PY'
-import sys, time, torch, math
+import sys, time, torch
 sys.path.insert(0, '.')
-from vtoonify_amd import _lib, kernels as K
+sys.path.insert(0, 'tests')
+from conftest import load_keys
+from vtoonify_amd import synth, _lib
+from vtoonify_amd.engine import VToonifyEngine
 _lib.use_library(_lib.DEFAULT_LIB)
 dev = torch.device('cuda:0')
-# operator surface: conv_transpose2d(3x3, stride 2) 512 -> 512 at 32x32 (StyledConv(upsample) of the reference, one frame): parity tiles vs gather form
-for N, cin, H, cout in ((1, 512, 32, 512), (4, 512, 32, 512), (1, 256, 128, 128)):
-    x = torch.randn(N, H, H, cin, device=dev).bfloat16()
-    w = (torch.randn(cout, 9, cin, device=dev) / math.sqrt(9 * cin)).bfloat16()
-    z = torch.zeros(N, 2 * H + 1, 2 * H + 1, cout, device=dev, dtype=torch.bfloat16)
-    for hint, name in ((0, "parity tiles"), (1000000000, "gather form")):
-        kw = dict(src0=x, c0=cin, ld0=cin, n=N, h=H, w=H, out_h=2 * H + 1, out_w=2 * H + 1, weight=w, cout=cout, kh=3, kw=3, stride=2, pad=0,
-                  transposed=1, out=z, ld_out=cout, dtype=K.VT_BF16, tile_hint=hint)
-        for _ in range(3): K.conv2d(**kw)
+sd = {k: v.to(dev) for k, v in synth.synth_state_dict(load_keys('D'), 0).items()}
+s = synth.synth_style(seed=17).to(dev)
+for B in (1, 4):
+    x = synth.synth_frames(B, 256, 256, seed=5).to(dev)
+    for name, kw in (('fp32', {}), ('f32x3', {'x3': True})):
+        eng = VToonifyEngine(sd, 'dualstylegan', 256, torch.float32, dev, **kw)
+        for _ in range(3): y = eng.forward(x, s, 0.5, shared_style=True, borrow=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20): K.conv2d(**kw)
-        torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 20 * 1e6
-        print(f"conv_transpose2d {cin}->{cout} @{H}x{H} batch {N}: {name:<13} {us:8.1f} us")
+        n = 20
+        for _ in range(n): y = eng.forward(x, s, 0.5, shared_style=True, borrow=True)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+        print(f"B={B} {name}: {1e3*dt:.3f} ms/step  {B/dt:.1f} frames/s (one step in flight)", flush=True)
+        if name == 'f32x3':
+            plan = eng.plan_for(B, 256, 256, True, True)
+            rows = {}
+            for info, ms in eng.time_ops(plan, 3):
+                k = info.get('kernel', '?'); rows[k] = rows.get(k, 0) + ms
+            for k, v in sorted(rows.items(), key=lambda kv: -kv[1])[:10]: print(f"     {k:<40} {v:.3f} ms")
+        del eng
 PY
+CB="python tools/conv_bench.py"
+echo "--- f32x3 tile choice on the 128-channel layers (fp32 dtype... conv_bench has no x3 flag: skipped)"

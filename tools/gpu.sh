@@ -13,7 +13,7 @@
 #   conv ARGS    tools/conv_bench.py ARGS   (quote ARGS as one word, e.g. "--stream --only res --batch 4")
 #   op           tools/op_bench.py bf16 + fp32
 #   sh CMD       arbitrary command (one word), e.g. "bash tools/ab.sh adain" (the A/B experiments of round 3)
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out
 B="python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-video --no-extras --min-seconds 0.3"

@@ -1931,7 +1931,9 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             // 32-pixel step of the weight-stationary kernel: 28.7 -> 24.5 us per conv before tuning, 66 -> 44 us for the
             // 1024 -> 512 fusion conv (profiles/r04_patch_pipeline.txt).  bf16 only (fp32 is MFMA-bound either way and keeps
             // the per-image plans of the parity mode); same rule as above for VT_BATCH_EXACT.
-            const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && a.dil == 1 &&
+            // (planes of at most 48 x 48 pixels -- the trunk of frames up to 1536^2: the measured case; two frames of a
+            // 64 x 64-pixel level would qualify by tile count, but were never measured against the weight-stationary kernel)
+            const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && a.dil == 1 && m1 <= 2304 &&
                                        a.coutT >= 128 && !a.tile_stats && !a.in_tile_stats && !a.stats_part &&
                                        (int64_t)a.N * ptiles(16, 32) >= 256 && !batch_exact() && patch_eligible<T>(a, g);
             if (batch_patch32) {
@@ -2269,7 +2271,11 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // software-pipelined form of the 256-pixel tiles (conv_patch_pipe.hpp; same K order, same bits).
             // VT_PATCH_PIPE=0: the per-tap form below (A/B; read per call: tests flip it)
             const char* e = getenv("VT_PATCH_PIPE");
-            const bool pipe = !(e && e[0] == '0') && !a.x3;   // (f32x3 runs the per-tap form: its instances live there)
+            // (f32x3 runs the per-tap form: a tap-granular pipelined f32x3 step -- split, LDS-DMA, next tap's raw fragments, 3 MFMAs
+            // per product -- measured SLOWER than it on the 64-channel tiles, 0.81 vs 0.51 ms per 4 frames, and 149 us per trunk
+            // conv on 32-channel tiles against 100 us on the whole-K kernel: with both waves of a SIMD splitting at the same
+            // time right after the barrier the VALU burst is exposed; profiles/r04_f32x3.txt)
+            const bool pipe = !(e && e[0] == '0') && !a.x3;
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
