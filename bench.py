@@ -286,9 +286,9 @@ def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
             "backend": getattr(O, "BACKEND", "numpy"),
             "repetitions_s": [round(t, 3) for t in reps],
-            "port_vs_reference": "profiles/r04_cpu_port_vs_reference.txt: on the same 8 cores the reference's own op_cpu path "
-                                 "(model/vtoonify.py:210-277 over model/stylegan/op_cpu) needs 0.7x the oracle's time per frame -- "
-                                 "this port UNDERSTATES the reference's CPU rate by about that factor",
+            "port_vs_reference": "profiles/r04_cpu_port_vs_reference.txt (authoring container, 8 idle cores, alternating): the "
+                                 "reference's own op_cpu path (model/vtoonify.py:210-277 over model/stylegan/op_cpu) 1.72 s per frame, this "
+                                 "oracle 2.60 s -- the port UNDERSTATES the reference's CPU rate by about 1.5x",
             "sample": f"1 frame 22x{h}x{w} -> 3x{4 * h}x{4 * w} fp32 through oracle/vtoonify_oracle.py, median of "
                       f"{len(reps)} runs = {dt:.2f} s, scaled x{(height * width) // (h * w)} in pixels to the "
                       f"22x{height}x{width} workload"}

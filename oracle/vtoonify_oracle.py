@@ -19,7 +19,9 @@ variance, eps inside the sqrt).
 
 All tensors are numpy fp32, NCHW, exactly the reference's layout.
 
-Backends for the three dense contractions (conv2d / conv_transpose2d / linear):
+Backends for the three dense contractions (conv2d / conv_transpose2d / linear) and, since round 4, for upfirdn2d,
+fused_leaky_relu, leaky_relu and instance_norm (the reference's op_cpu path runs all of them through torch on CPU threads:
+with only the contractions on torch the oracle needed 3.3x the reference's time per frame, profiles/r04_cpu_port_vs_reference.txt):
   "numpy"  (default) the plain restatement below -- one BLAS matmul per filter tap;
   "torch"  the very functions the reference calls, torch.nn.functional.conv2d /
            conv_transpose2d / linear on CPU tensors (op/conv2d_gradfix.py:34-42,66-75,
@@ -80,6 +82,23 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     px0, px1, py0, py1 = (int(p) for p in pad)
     n, c, in_h, in_w = x.shape
     kh, kw = kernel.shape
+    if BACKEND == "torch":
+        # the same steps through the torch functions op_cpu/upfirdn2d.py:27-58 itself calls (F.pad for the zero insertion
+        # and the positive pads, slicing for the negative ones, F.conv2d with the flipped kernel, strided slicing): what the
+        # reference's CPU path executes, multi-threaded -- bench.py's cpu_baseline times this form
+        import torch
+        import torch.nn.functional as TF
+        t = _t(x).reshape(n * c, in_h, 1, in_w, 1)
+        t = TF.pad(t, [0, up_x - 1, 0, 0, 0, up_y - 1]).reshape(n * c, 1, in_h * up_y, in_w * up_x)
+        t = TF.pad(t, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+        t = t[:, :, max(-py0, 0): t.shape[2] - max(-py1, 0), max(-px0, 0): t.shape[3] - max(-px1, 0)]
+        if t.shape[2] < kh or t.shape[3] < kw:
+            oh = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
+            ow = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
+            return np.zeros((n, c, max(oh, 0), max(ow, 0)), dtype=F32)
+        t = TF.conv2d(t, torch.flip(_t(kernel), [0, 1])[None, None])
+        t = t[:, :, ::down_y, ::down_x]
+        return np.ascontiguousarray(t.reshape(n, c, t.shape[2], t.shape[3]).numpy())
 
     # zero insertion (op_cpu/upfirdn2d.py:30-32)
     z = np.zeros((n, c, in_h * up_y, in_w * up_x), dtype=F32)
@@ -107,6 +126,12 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
 def fused_leaky_relu(x, bias=None, negative_slope=0.2, scale=2 ** 0.5):
     """leaky_relu(x + b[c]) * scale, bias broadcast on dim 1 (op_cpu/fused_act.py:23-34)."""
     x = np.asarray(x, dtype=F32)
+    if BACKEND == "torch":   # F.leaky_relu(input + bias) * scale, op_cpu/fused_act.py:27-34
+        import torch.nn.functional as TF
+        t = _t(x)
+        if bias is not None:
+            t = t + _t(bias).reshape((1, -1) + (1,) * (x.ndim - 2))
+        return (TF.leaky_relu(t, negative_slope) * F32(scale)).numpy()
     if bias is not None:
         b = np.asarray(bias, dtype=F32).reshape((1, -1) + (1,) * (x.ndim - 2))
         x = x + b
@@ -180,12 +205,18 @@ def linear(x, w, b=None):
 def instance_norm(x, eps=1e-5):
     """nn.InstanceNorm2d(affine=False): per (n,c) biased variance (dualstylegan.py:10)."""
     x = np.asarray(x, dtype=F32)
+    if BACKEND == "torch":
+        import torch.nn.functional as TF
+        return TF.instance_norm(_t(x), eps=eps).numpy()
     mean = x.mean(axis=(2, 3), keepdims=True, dtype=np.float64)
     var = ((x - mean) ** 2).mean(axis=(2, 3), keepdims=True, dtype=np.float64)
     return ((x - mean) / np.sqrt(var + eps)).astype(F32)
 
 
 def leaky_relu(x, slope=0.2):
+    if BACKEND == "torch":
+        import torch.nn.functional as TF
+        return TF.leaky_relu(_t(x), slope).numpy()
     return np.where(x >= 0, x, x * F32(slope)).astype(F32)
 
 

@@ -72,10 +72,11 @@ def main():
     ap.add_argument("--adain", type=int, default=0,
                     help="whole-K trunk convs: bit 0 = AdaIN consumer (in_tile_stats + in_gb), bit 1 = emit tile_stats, bit 2 = residual")
     ap.add_argument("--rgb", action="store_true", help="attach the fused ToRGB epilogue to the same-resolution convs")
+    ap.add_argument("--lib", default="", help="another build of the library (same-box A/B of two .so files)")
     ap.add_argument("--sweep", default="", help="VAR=a,b,c: time every shape under each value of an environment switch the "
                     "library reads per call (same process, same buffers: a same-box A/B)")
     args = ap.parse_args()
-    _lib.use_library(_lib.DEFAULT_LIB)
+    _lib.use_library(args.lib or _lib.DEFAULT_LIB)
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     esz = 2 if dt == torch.bfloat16 else 4
