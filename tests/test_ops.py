@@ -602,6 +602,50 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
         assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < (F32_TOL if dtype == torch.float32 else 8e-3)
 
 
+def test_conv_patch_weights_resident_equals_pipelined(dev, monkeypatch):
+    """conv_patchw_kernel (csrc/conv_patch_resident.hpp): single-chunk layers (Cin = 64 bf16) on 256 x 64 tiles with all 9 taps
+    of the weights resident in LDS and persistent workgroups that walk tiles with the next patch in flight.  Same K order as
+    the pipelined / per-tap forms -> the same bits in the activation.  VT_PATCHW_WGS makes small convolutions walk several tiles per workgroup:
+    3 (plain striding), 8 and 16 (tile ranges per XCD, one / two workgroups each), odd and even tile counts per workgroup (the
+    two 4-wave groups of a workgroup take alternate tiles), ragged edges, a batch, bias + LeakyReLU, the fused ToRGB epilogue."""
+    dtype = torch.bfloat16
+    g = np.random.default_rng(41)
+    for N, H, W, cout, wgs, rgb in ((1, 40, 50, 64, 3, False), (2, 33, 47, 64, 8, True), (1, 80, 100, 64, 16, False),
+                                    (3, 17, 31, 64, 2, True)):
+        cin = 64
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xa = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        ldo = (cout + 7) // 8 * 8
+        rgbw = K.pack_conv_weight(T((g.standard_normal((3, cout, 1, 1)) / 8).astype(np.float32), dev), out_dtype=dtype)
+        skip = T(g.standard_normal((N, 3, H, W)).astype(np.float32), dev)
+        rgbb = T(g.standard_normal(3).astype(np.float32), dev)
+
+        def run():
+            out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
+            rgb_out = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
+            kw = dict(rgb_weight=rgbw, rgb_bias=rgbb, rgb_resid=skip, rgb_out=rgb_out) if rgb else {}
+            K.conv2d(src0=xa, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, alpha=0.5, out=out, ld_out=ldo, dtype=K.dt_code(dtype),
+                     tile_hint=P + 256064, **kw)
+            return out, rgb_out
+        monkeypatch.setenv("VT_PATCHW_WGS", str(wgs))
+        got, got_rgb = run()
+        monkeypatch.setenv("VT_PATCH_PIPE", "1")
+        ref, ref_rgb = run()
+        monkeypatch.delenv("VT_PATCH_PIPE")
+        monkeypatch.delenv("VT_PATCHW_WGS")
+        # (the ToRGB sums run over 64 channels in ONE wave here, over two waves' halves through LDS there: same terms, another
+        # association -- the image agrees to fp32 rounding, the activation bit for bit)
+        assert torch.equal(got, ref), (N, H, W, cout, wgs)
+        assert rel_err(got_rgb.cpu().numpy(), ref_rgb.cpu().numpy()) < 2e-6, (N, H, W, cout, wgs)
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        y = O.leaky_relu(O.conv2d(xa.float().cpu().permute(0, 3, 1, 2).numpy(), wq, b, 1, 1, 1), 0.2) * np.float32(2 ** 0.5) * 0.5
+        assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), y) < 8e-3
+
+
 def test_conv_f32x3(dev):
     """vt_conv_desc.dtype = VT_F32X3 (ABI 5): fp32 tensors, every product as three bf16 MFMAs (bf16 head / remainder split of
     both operands in the fragment registers).  Patch tiles, the direct-to-LDS 1-D kernel (stride 2) and the whole-K kernel

@@ -443,10 +443,12 @@ __device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n,
 template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               unsigned char* smem, const RowMap rowmap, int n0, int split,
-                                              int tile_id) {
+                                              int tile_id, int tid_in = -1) {
+    // tid_in: thread index within the group of WM x WN waves that owns this tile when that is not the workgroup
+    // (conv_patchw_kernel: two 4-wave groups per workgroup)
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr bool PERM = (TN % 2 == 0);
-    const int tid = threadIdx.x;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, l15 = lane & 15;
@@ -1444,6 +1446,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #include "conv_upblur.hpp"
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
+#include "conv_patch_resident.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -1843,6 +1846,19 @@ static bool c32_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
+// VT_BATCH_EXACT=1: no plan choice that makes a frame inside a batch differ (in rounding) from the frame alone
+static bool batch_exact() {
+    const char* be = getenv("VT_BATCH_EXACT");   // read per call: tests flip it
+    return be && be[0] == '1';
+}
+
+// persistent workgroups of the weights-resident form: one per CU.  VT_PATCHW_WGS (read per call): tests use a few workgroups
+// so that small convolutions walk several tiles each
+static int patchw_wgs() {
+    const char* e = getenv("VT_PATCHW_WGS");
+    return e && atoi(e) > 0 ? atoi(e) : 256;
+}
+
 template <typename T>
 static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -1889,11 +1905,6 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
     auto tiles = [&](int m, int n) { return (int64_t)vt_cdiv(m1, m) * vt_cdiv(a.coutT, n); };
     auto ptiles = [&](int th, int n) {
         return (int64_t)vt_cdiv(a.Ho, th) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, n);
-    };
-    // VT_BATCH_EXACT=1: no plan choice that makes a frame inside a batch differ (in rounding) from the frame alone
-    auto batch_exact = [] {
-        const char* be = getenv("VT_BATCH_EXACT");   // read per call: tests flip it
-        return be && be[0] == '1';
     };
     GldsArgs g;
     if (hp != 2 && hbm == 0 && c32_eligible<T>(a, g)) {   // the 1024^2 level: persistent register-weight kernel
@@ -2125,6 +2136,24 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
+// weights-resident persistent form (conv_patch_resident.hpp): one chunk of K, one channel tile, no split
+template <typename T, int TH, int BN>
+int launch_patchw(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    ConvArgs args = a;
+    args.slab_perm = ((BN / 16) % 2 == 0) ? 1 : 0;
+    args.tiles_n = 1;
+    args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
+    args.kps = 1;
+    args.splitk = 1;
+    split_mode(args);
+    int wgs = patchw_wgs();
+    if (wgs > args.tiles_m) wgs = args.tiles_m;
+    if (wgs >= 8) wgs &= ~7;                    // whole XCD rounds: the kernel hands out tiles per XCD
+    auto k = conv_patchw_kernel<T, TH, BN>;
+    VT_LAUNCH(k, dim3((unsigned)wgs), dim3(512), stream, args, g);
+    return vt_check_launch("vt_conv2d(patch, weights resident)");
+}
+
 template <typename T>
 int launch_c32(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     ConvArgs args = a;
@@ -2276,6 +2305,18 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // conv on 32-channel tiles against 100 us on the whole-K kernel: with both waves of a SIMD splitting at the same
             // time right after the barrier the VALU burst is exposed; profiles/r04_f32x3.txt)
             const bool pipe = !(e && e[0] == '0') && !a.x3;
+            // one chunk of K, one channel tile, several tiles per CU: weights resident, persistent workgroups (VT_PATCH_PIPE=1:
+            // the plain pipelined form, A/B)
+            if constexpr (sizeof(T) == 2) {
+                // (lean epilogue: bf16 NHWC vector stores of all 64 channels, bias + (Leaky)ReLU * gain, optional fused ToRGB)
+                const bool lean = a.coutT == 64 && a.phases == 1 && a.out_layout == VT_OUT_NHWC && !a.out_f32 && a.vec_store &&
+                                  a.ld_out % 8 == 0 && !a.resid && !a.slope_vec && !a.alpha_dev && !a.post_relu && !a.stats_part &&
+                                  (a.act == VT_ACT_NONE || a.act == VT_ACT_LRELU);
+                if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && t.bn == 64 && units == 1 && lean && !a.src1 &&
+                    a.splitk <= 1 &&
+                    (int64_t)(batch_exact() ? 1 : a.N) * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) >= 2 * patchw_wgs())
+                    return launch_patchw<T, 16, 64>(a, g, stream);
+            }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);

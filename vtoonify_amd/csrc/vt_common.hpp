@@ -244,6 +244,20 @@ __device__ __forceinline__ void vt_ticket_store(int* p, int v) {
 }
 #endif
 
+// optimisation barriers on a value: the compiler must treat it as unknown from here on (keeps loop-invariant
+// address arithmetic / table loads inside a persistent kernel's tile loop instead of hoisting them into registers)
+#ifdef VT_EMU
+template <typename V>
+static inline void vt_opaque(V&) {}
+template <typename V>
+static inline void vt_opaque_ptr(V*&) {}
+#else
+template <typename V>
+__device__ __forceinline__ void vt_opaque(V& v) { asm volatile("" : "+v"(v)); }
+template <typename V>
+__device__ __forceinline__ void vt_opaque_ptr(V*& v) { asm volatile("" : "+s"(v)); }
+#endif
+
 #ifdef VT_EMU
 static inline void vt_sched_fence() {}
 template <int MASK, int N>
