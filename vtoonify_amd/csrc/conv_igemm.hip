@@ -2311,7 +2311,9 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                 // (lean epilogue: bf16 NHWC vector stores of all 64 channels, bias + (Leaky)ReLU * gain, optional fused ToRGB)
                 const bool lean = a.coutT == 64 && a.phases == 1 && a.out_layout == VT_OUT_NHWC && !a.out_f32 && a.vec_store &&
                                   a.ld_out % 8 == 0 && !a.resid && !a.slope_vec && !a.alpha_dev && !a.post_relu && !a.stats_part &&
-                                  (a.act == VT_ACT_NONE || a.act == VT_ACT_LRELU);
+                                  (a.act == VT_ACT_NONE || a.act == VT_ACT_LRELU) &&
+                                  (int64_t)a.N * a.Ho * a.Wo * a.ld_out * 2 < (((int64_t)1 << 31) - 4096) &&   // counted buffer stores
+                                  (int64_t)a.N * a.Ho * a.Wo * 12 < (((int64_t)1 << 31) - 4096);
                 if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && t.bn == 64 && units == 1 && lean && !a.src1 &&
                     a.splitk <= 1 &&
                     (int64_t)(batch_exact() ? 1 : a.N) * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) >= 2 * patchw_wgs())

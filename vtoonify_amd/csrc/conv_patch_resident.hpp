@@ -90,8 +90,7 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
     // patch of tile `tm` -> this group's patch buffer
     const int aoff = A_OFF + grp * A_BYTES;
     auto issue_patch = [&](int tm) {
-        int lrow = lane >> 3;
-        vt_opaque(lrow);   // (the 2 x PA patch coordinates of a lane are loop-invariant too: recomputed, not kept)
+        const int lrow = vt_opaque(lane >> 3);   // (the 2 x PA patch coordinates of a lane are loop-invariant: recomputed per tile, not kept)
         const int jj = (lane & 7) ^ lrow;
         const int im = tm / per_img, tr = tm - im * per_img;
         const int ty0 = (tr / tiles_x) * TH, tx0 = (tr % tiles_x) * TW;
@@ -119,6 +118,10 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
     float rb[3] = {0.0f, 0.0f, 0.0f};
     if (rgbf && p.rgb_bias) rb[0] = p.rgb_bias[0], rb[1] = p.rgb_bias[1], rb[2] = p.rgb_bias[2];
     const int HoWo = p.Ho * p.Wo;
+    // (the host checked that the three tensors are below 2 GB; a null skip reads as zeros)
+    const BufRaw rout = vt_make_raw(p.out, (uint32_t)((int64_t)p.M * p.ld_out * ESZ));
+    const BufRaw rskip = vt_make_raw(p.rgb_resid, (uint32_t)((int64_t)p.N * 3 * HoWo * 4));
+    const BufRaw rimg = vt_make_raw(p.rgb_out, (uint32_t)((int64_t)p.N * 3 * HoWo * 4));
 
     const int q = lane >> 4, l15 = lane & 15, l7 = lane & 7;
     uint32_t aswz[8][2];
@@ -187,6 +190,10 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
         // (bias + LeakyReLU * gain -> bf16 NHWC, optional fused ToRGB: the host admits nothing else.  The generic conv_epilogue
         // in this loop hoisted ~100 registers of per-lane invariants out of it and spilled them; every reload is a vmcnt(0)
         // that also drains the patch in flight: 154 us instead of 110 for the one-group form)
+        // Every vector-memory operation of the slot is hidden from the compiler and COUNTED (vt_common.hpp): beside the LDS-DMA
+        // in flight hipcc would wait vmcnt(0) at the first use of the skip pixels, and the slot would end by waiting for the
+        // acknowledgement of its own stores.  Order: patch pieces, [3 skip loads], 8 activation stores, [3 image stores]; the
+        // wave leaves the slot when everything older than its stores has landed -- the patch, which is what the next M needs.
         if (j + 1 < ng) issue_patch(tile_of(j + 1));
         {
             const int tm = tile_of(j);
@@ -194,16 +201,15 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
             const PatchRows<TW> rowmap{im, (tr / tiles_x) * TH, (tr % tiles_x) * TW, p.Ho, p.Wo};
             // lane (q, l15) finishes the ToRGB of tile row q of its wave (reduce-scatter below): its skip pixel is fetched now
             const int m_rgb = rowmap(wm * (TM * 16) + q * 16 + l15);
-            int64_t o_rgb = 0;
-            {
-                const int mm = m_rgb < 0 ? 0 : m_rgb;
-                const int ii = mm / HoWo;
-                o_rgb = (int64_t)ii * 3 * HoWo + (mm - ii * HoWo);
+            uint32_t o_rgb = GLDS_OOB;
+            if (m_rgb >= 0) {
+                const int ii = m_rgb / HoWo;
+                o_rgb = (uint32_t)(ii * 3 * HoWo + (m_rgb - ii * HoWo)) * 4u;
             }
-            float rsd[3] = {0.0f, 0.0f, 0.0f};
-            if (rgbf && p.rgb_resid) {
+            u128 rsd[3];
+            if (rgbf) {
 #pragma unroll
-                for (int jc = 0; jc < 3; ++jc) rsd[jc] = p.rgb_resid[o_rgb + (int64_t)jc * HoWo];
+                for (int jc = 0; jc < 3; ++jc) vt_bload_hidden<1>(rsd[jc], rskip, m_rgb >= 0 ? o_rgb + (uint32_t)(jc * HoWo) * 4u : GLDS_OOB);
             }
             const float ga = p.gain_alpha;
             const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
@@ -234,7 +240,7 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) rp[a][0] += f[i] * w0[i], rp[a][1] += f[i] * w1[i], rp[a][2] += f[i] * w2[i];
                     }
-                    if (m >= 0 && !p.rgb_only) st128((T*)p.out + (int64_t)m * p.ld_out + c0, pack16<T>(f));
+                    vt_bstore_hidden<4>(rout, m >= 0 ? (uint32_t)(m * p.ld_out + c0) * (uint32_t)ESZ : GLDS_OOB, pack16<T>(f));
                 }
             }
             if (rgbf) {
@@ -254,14 +260,17 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
                     keep += __shfl_xor(send, 16, 64);
                     rr[jc] = keep;
                 }
-                if (m_rgb >= 0) {
-                    p.rgb_out[o_rgb] = rr[0] + rb[0] + rsd[0];
-                    p.rgb_out[o_rgb + HoWo] = rr[1] + rb[1] + rsd[1];
-                    p.rgb_out[o_rgb + 2 * (int64_t)HoWo] = rr[2] + rb[2] + rsd[2];
+                vt_vmcnt_fence<2 * TM>();   // the skip pixels (and with them the patch: older) have landed; 8 stores may fly
+#pragma unroll
+                for (int jc = 0; jc < 3; ++jc) {
+                    u128 o;
+                    o.x = vt_f2u((rr[jc] + rb[jc]) + vt_u2f(vt_settled(rsd[jc]).x)), o.y = o.z = o.w = 0u;
+                    vt_bstore_hidden<1>(rimg, m_rgb >= 0 ? o_rgb + (uint32_t)(jc * HoWo) * 4u : GLDS_OOB, o);
                 }
+            } else {
+                vt_vmcnt_fence<2 * TM>();   // the patch has landed; the 8 stores may fly
             }
         }
-        vt_glds_wait_n<0>();
         vt_lds_barrier();
     }
     // both groups leave after the same number of barriers (nmine + 1)

@@ -244,20 +244,6 @@ __device__ __forceinline__ void vt_ticket_store(int* p, int v) {
 }
 #endif
 
-// optimisation barriers on a value: the compiler must treat it as unknown from here on (keeps loop-invariant
-// address arithmetic / table loads inside a persistent kernel's tile loop instead of hoisting them into registers)
-#ifdef VT_EMU
-template <typename V>
-static inline void vt_opaque(V&) {}
-template <typename V>
-static inline void vt_opaque_ptr(V*&) {}
-#else
-template <typename V>
-__device__ __forceinline__ void vt_opaque(V& v) { asm volatile("" : "+v"(v)); }
-template <typename V>
-__device__ __forceinline__ void vt_opaque_ptr(V*& v) { asm volatile("" : "+s"(v)); }
-#endif
-
 #ifdef VT_EMU
 static inline void vt_sched_fence() {}
 template <int MASK, int N>
@@ -495,7 +481,7 @@ __device__ __forceinline__ void vt_bload_hidden(u128& v, const BufRaw& r, uint32
 // AUX = cache policy of the store (A/B knob): 0 default, 1 nt, 2 sc1, 3 sc0 sc1
 template <int DW, int AUX = 0>
 __device__ __forceinline__ void vt_bstore_hidden(const BufRaw& r, uint32_t voff, const u128& v) {
-    static_assert(DW == 2 || DW == 4, "dwords per lane");
+    static_assert(DW == 1 || DW == 2 || DW == 4, "dwords per lane");
 #define VT_BST(OP_, X_)                                                                                                   \
     if constexpr (AUX == 1) asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen nt" ::"v"(X_), "v"(voff), "s"(r.v) : "memory");          \
     else if constexpr (AUX == 2) asm volatile("s_nop 4\n\t" OP_ " %0, %1, %2, 0 offen sc1" ::"v"(X_), "v"(voff), "s"(r.v) : "memory");    \
@@ -504,10 +490,13 @@ __device__ __forceinline__ void vt_bstore_hidden(const BufRaw& r, uint32_t voff,
     if constexpr (DW == 4) {
         const vt_u32x4 x = __builtin_bit_cast(vt_u32x4, v);
         VT_BST("buffer_store_dwordx4", x)
-    } else {
+    } else if constexpr (DW == 2) {
         typedef uint32_t vt_u32x2 __attribute__((ext_vector_type(2)));
         const vt_u32x2 x = {v.x, v.y};
         VT_BST("buffer_store_dwordx2", x)
+    } else {
+        const uint32_t x = v.x;
+        VT_BST("buffer_store_dword", x)
     }
 #undef VT_BST
 }
