@@ -408,7 +408,9 @@ __device__ __forceinline__ int frag_channel(int b, int q) {  // first of the 4 c
 }
 
 // Eight consecutive output columns n..n+7 of GEMM row m (bf16 NHWC, vector path): one 16-byte store.
-__device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n, float* f) {
+__device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n, float* f, bool have_rpre = false,
+                                                u128 rpre = u128{0u, 0u, 0u, 0u}) {
+    // rpre (have_rpre): the residual vector of this store, fetched by the caller ahead of ALL its stores
     if (p.out_layout != VT_OUT_NHWC || p.out_f32 || !p.vec_store) return false;
     const int HoWo = p.Ho * p.Wo;
     int64_t opix = m;
@@ -426,13 +428,88 @@ __device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n,
     bf16_t* o = (bf16_t*)p.out + opix * p.ld_out + co;
     if (p.resid) {
         float g[8];
-        unpack16<bf16_t>(ld128((const bf16_t*)p.resid + opix * p.ld_res + co), g);
+        unpack16<bf16_t>(have_rpre ? rpre : ld128((const bf16_t*)p.resid + opix * p.ld_res + co), g);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] += p.beta * g[i];
     }
     post_act_n<8>(p, f);
     st128(o, pack16<bf16_t>(f));
     return true;
+}
+
+// fused-ToRGB weights of the 8 channels a lane holds in fragment pair (b0, b0 + 1): [h][rgb][i], zero beyond coutT
+template <typename T, bool PERM>
+__device__ __forceinline__ void rgb_pair_weights(const ConvArgs& p, int nbase, int b0, int q, float (&w)[2][3][4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = nbase + frag_channel<PERM>(b0 + h, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nc = (n + i < p.coutT) ? n + i : p.coutT - 1;   // clamped: loads stay unconditional
+            const float live = (n + i < p.coutT) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) w[h][j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
+        }
+    }
+}
+
+// Per-lane epilogue tables: bias and activation slope of the lane's 4 channels of every fragment column, and the gain.
+// ALL of them are fetched in one batch (one memory round trip) -- and, in the kernels that can afford the registers, before
+// the K loop, so that the round trip is hidden by it.  Fetched per fragment pair inside the finishing loop they were three
+// dependent round trips at the end of every workgroup (alpha, tables of the first pair, tables of the second pair), each
+// behind the acknowledgement of the stores issued before it: measured on the 256 x 128 patch tiles, same box, the epilogue
+// cost 9-14 us per round of 256 workgroups (profiles/r04_epilogue.txt).
+template <int TN>
+struct EpiTables {
+    float bv[TN][4], sv[TN][4];
+    float ga;
+};
+template <int TN, bool PERM>
+__device__ __forceinline__ void epi_tables(const ConvArgs& p, int nbase, int q, EpiTables<TN>& t) {
+    // nbase = n0 + wn * (TN * 16): first channel of the wave's fragment columns
+    int coi[TN][4];
+    bool okc[TN][4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nn = nbase + frag_channel<PERM>(b, q) + i;
+            okc[b][i] = nn < p.coutT;
+            const int nc = okc[b][i] ? nn : 0;
+            coi[b][i] = (p.phases > 1) ? nc % p.cout : nc;
+        }
+    // ONE wave-uniform branch per table and unconditional loads at clamped indices inside it.  (The per-element form
+    // `(ptr && nn < coutT) ? ptr[co] : 0` makes hipcc branch around every load and wait vmcnt(0) for it.)
+    float al = 1.0f;
+    if (p.alpha_dev) al = p.alpha_dev[0];
+    if (p.bias) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.bv[b][i] = p.bias[coi[b][i]];
+    } else {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.bv[b][i] = 0.0f;
+    }
+    if (p.slope_vec) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.sv[b][i] = p.slope_vec[coi[b][i]];
+    } else {
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.sv[b][i] = p.slope;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!okc[b][i]) t.bv[b][i] = 0.0f, t.sv[b][i] = p.slope;
+    t.ga = p.gain_alpha * al;
 }
 
 // Epilogue straight from the accumulators.  The kernels issue the MFMAs with the operands
@@ -443,12 +520,12 @@ __device__ __forceinline__ bool store_out8_bf16(const ConvArgs& p, int m, int n,
 template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               unsigned char* smem, const RowMap rowmap, int n0, int split,
-                                              int tile_id, int tid_in = -1) {
-    // tid_in: thread index within the group of WM x WN waves that owns this tile when that is not the workgroup
-    // (conv_patchw_kernel: two 4-wave groups per workgroup)
+                                              int tile_id, const EpiTables<BN / WN / 16>& tab) {
+    // tab: the lane's bias / slope / gain tables (epi_tables) -- fetched by the caller before its K loop where it can afford
+    // the registers, else by the overload below right here
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr bool PERM = (TN % 2 == 0);
-    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, l15 = lane & 15;
@@ -522,7 +599,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         }
         // fall through to the fused epilogue below
     }
-    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    const float ga = tab.ga;
     // Fused ToRGB (model/stylegan/model.py:383-392): when this tile holds ALL output channels of its
     // pixels, the 1x1 modulated conv C -> 3 that follows a same-resolution StyledConv is three dot
     // products over values that are already in registers -- the C-channel activation (67 MB at the
@@ -532,51 +609,113 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
     for (int a = 0; a < TM; ++a) rp[a][0] = rp[a][1] = rp[a][2] = 0.0f;
     constexpr int BS = PERM ? 2 : 1;   // fragments finished together: under PERM a pair = 8 consecutive channels
+    // residual vectors of every 16-byte bf16 store, ahead of the first store (loads at clamped addresses: no branch per
+    // element).  Fetched inside store_out8_bf16 each was a round trip behind the acknowledgement of the store before it.
+    constexpr int NPAIR = (TN + BS - 1) / BS;
+    u128 rpre[NPAIR][TM];
+    const bool rvec = BS == 2 && sizeof(T) == 2 && p.resid && p.phases == 1 && p.out_layout == VT_OUT_NHWC && !p.out_f32 &&
+                      p.vec_store && !((p.ld_out | p.ld_res) & 7);
+    if (rvec) {
+#pragma unroll
+        for (int b0 = 0; b0 < TN; b0 += BS) {
+            const int nn = n0 + wn * (TN * 16) + frag_channel<PERM>(b0, q);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+                const bool ok = m >= 0 && nn + 8 <= p.coutT;
+                rpre[b0 / BS][a] = ld128((const bf16_t*)p.resid + (int64_t)(ok ? m : 0) * p.ld_res + (ok ? nn : 0));
+            }
+        }
+    }
+    // Lean path: (Leaky)ReLU or no activation, bf16 NHWC rows of whole 16-byte vectors -- every 3x3 conv of the frame's hot
+    // kernels.  Branch-free per value (the activation is a select against a slope of 1 where there is none).  The general
+    // loop below runs conv_finish / store_out8_bf16 per value and per store: wave-uniform, but ~10 scalar branches per
+    // value, 20 000 lines of ISA for a 64 x 64 wave tile -- the epilogue of the 256 x 128 patch tiles cost 9-14 us per round
+    // of 256 workgroups (37 of 102 us on the 128 -> 128 conv at 256^2, profiles/r04_epilogue.txt), and it was neither
+    // its table loads nor its stores.
+    bool lean = false;
+    if constexpr (BS == 2) {
+        constexpr bool H = sizeof(T) == 2;   // bf16 rows (one 16-byte store per 8 channels) or fp32 rows (two)
+        lean = (p.act == VT_ACT_NONE || p.act == VT_ACT_LRELU) && p.phases == 1 && p.out_layout == VT_OUT_NHWC &&
+               (H ? !p.out_f32 : p.out_f32 != 0) && p.vec_store && !p.post_relu && !(p.coutT & 7) &&
+               (H ? (!p.resid || rvec) && !(p.ld_out & 7) : !(p.ld_out & 3) && (!p.resid || !(p.ld_res & 3)));
+        if (lean) {
+            const bool lrelu = p.act == VT_ACT_LRELU;
+#pragma unroll
+            for (int b0 = 0; b0 < TN; b0 += 2) {
+                const int nn = n0 + wn * (TN * 16) + frag_channel<PERM>(b0, q);
+                float bb[8], se[8], wq[2][3][4];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bb[k] = tab.bv[b0 + (k >> 2)][k & 3];
+                    se[k] = lrelu ? tab.sv[b0 + (k >> 2)][k & 3] : 1.0f;
+                }
+                if (rgbf) rgb_pair_weights<T, PERM>(p, n0 + wn * (TN * 16), b0, q, wq);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
+                    float f[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float v = acc[a][b0 + (k >> 2)][k & 3] + bb[k];
+                        v = (v > 0.0f) ? v : v * se[k];
+                        f[k] = v * ga;
+                    }
+                    if (rgbf) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                rp[a][j] += (f[4 * h] * wq[h][j][0] + f[4 * h + 1] * wq[h][j][1]) +
+                                            (f[4 * h + 2] * wq[h][j][2] + f[4 * h + 3] * wq[h][j][3]);
+                    }
+                    const bool live = m >= 0 && nn + 8 <= p.coutT;
+                    if constexpr (H) {
+                        if (rvec) {
+                            float g[8];
+                            unpack16<bf16_t>(rpre[b0 / 2][a], g);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) f[k] += p.beta * g[k];
+                        }
+                        if (live) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + nn, pack16<bf16_t>(f));
+                    } else {
+                        if (p.resid) {   // (fp32: the residual of a pixel is fetched here, at a clamped address)
+                            const float* rs = (const float*)p.resid + (int64_t)(live ? m : 0) * p.ld_res + (live ? nn : 0);
+                            float g[8];
+                            unpack16<float>(ld128(rs), g), unpack16<float>(ld128(rs + 4), g + 4);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) f[k] += p.beta * g[k];
+                        }
+                        if (live) {
+                            float* o = (float*)p.out + (int64_t)m * p.ld_out + nn;
+                            st128(o, pack16<float>(f)), st128(o + 4, pack16<float>(f + 4));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!lean) {
 #pragma unroll
     for (int b0 = 0; b0 < TN; b0 += BS) {
         int nh[BS];
         float bv[BS][4], sv[BS][4], wr[BS][3][4];
 #pragma unroll
         for (int h = 0; h < BS; ++h) {
-            const int n = n0 + wn * (TN * 16) + frag_channel<PERM>(b0 + h, q);
-            nh[h] = n;
-            // bias / per-channel slope: ONE wave-uniform branch per table and unconditional loads at clamped indices
-            // inside it.  (The per-element form `(ptr && nn < coutT) ? ptr[co] : 0` makes hipcc branch around every load
-            // and wait vmcnt(0) for it: 4 x TN dependent L2 round trips at the end of every workgroup.)
-            int coi[4];
-            bool okc[4];
+            nh[h] = n0 + wn * (TN * 16) + frag_channel<PERM>(b0 + h, q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nn = n + i;
-                okc[i] = nn < p.coutT;
-                const int nc = okc[i] ? nn : 0;
-                coi[i] = (p.phases > 1) ? nc % p.cout : nc;
-            }
-            if (p.bias) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[h][i] = p.bias[coi[i]];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[h][i] = 0.0f;
-            }
-            if (p.slope_vec) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sv[h][i] = p.slope_vec[coi[i]];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sv[h][i] = p.slope;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!okc[i]) bv[h][i] = 0.0f, sv[h][i] = p.slope;
-            }
+            for (int i = 0; i < 4; ++i) bv[h][i] = tab.bv[b0 + h][i], sv[h][i] = tab.sv[b0 + h][i];
+        }
+        if constexpr (BS == 2) {
+            if (rgbf) rgb_pair_weights<T, PERM>(p, n0 + wn * (TN * 16), b0, q, wr);
+        } else {
             if (rgbf) {   // wave-uniform: convs without the fusion pay one scalar branch per fragment column
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int nc = (n + i < p.coutT) ? n + i : p.coutT - 1;   // clamped: loads stay unconditional
-                    const float live = (n + i < p.coutT) ? 1.0f : 0.0f;
+                    const int nc = (nh[0] + i < p.coutT) ? nh[0] + i : p.coutT - 1;   // clamped: loads stay unconditional
+                    const float live = (nh[0] + i < p.coutT) ? 1.0f : 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) wr[h][j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
+                    for (int j = 0; j < 3; ++j) wr[0][j][i] = to_f32(((const T*)p.rgb_w)[j * p.coutT + nc]) * live;
                 }
             }
         }
@@ -596,12 +735,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                                     (f[4 * h + 2] * wr[h][j][2] + f[4 * h + 3] * wr[h][j][3]);
                 }
             }
-            if (BS == 2 && nh[1] < p.coutT && store_out8_bf16(p, m, nh[0], f)) continue;
+            if (BS == 2 && nh[1] < p.coutT && store_out8_bf16(p, m, nh[0], f, rvec, rpre[b0 / BS][a])) continue;
 #pragma unroll
             for (int h = 0; h < BS; ++h)
                 if (nh[h] < p.coutT) store_out4(p, m, nh[h], f + 4 * h);
         }
     }
+    }   // !lean
     if (!rgbf) return;
     // up-sampled skip + bias of the pixels this lane writes: ALL loads issued here, unconditional at clamped offsets under
     // wave-uniform branches, so that they fly during the shuffles / the LDS exchange below.  (`if (p.rgb_resid) v +=
@@ -666,6 +806,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
         for (int j = 0; j < 3; ++j) p.rgb_out[roff[a] + (int64_t)j * HoWo] = (rp[a][j] + rb[j]) + rsd[a][j];
     }
+}
+
+// the same with the tables fetched here (one batch)
+template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
+                                              unsigned char* smem, const RowMap rowmap, int n0, int split, int tile_id) {
+    constexpr int TN = BN / WN / 16;
+    EpiTables<TN> tab;
+    const int tid = threadIdx.x;
+    epi_tables<TN, (TN % 2 == 0)>(p, n0 + ((tid >> 6) % WN) * (TN * 16), (tid & 63) >> 4, tab);
+    conv_epilogue<T, BM, BN, WM, WN>(p, acc, smem, rowmap, n0, split, tile_id, tab);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>

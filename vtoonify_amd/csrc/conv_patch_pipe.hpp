@@ -196,6 +196,10 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) Mma<T>::run(acc[cls][a][b], xb[b], xa[a]);
     };
+    // the epilogue's per-lane tables (bias, slope, gain): fetched here, used after the K loop -- their memory round trip was the
+    // first of three at the end of every workgroup
+    EpiTables<TN> etab;
+    epi_tables<TN, PERM>(p, n0 + wn * (TN * 16), q, etab);
     // ---- prologue: patch of the first chunk, weights of taps 0..2; patch + taps 0, 1 landed -------------
 #pragma unroll
     for (int i = 0; i < PA; ++i) issue_a_piece(ch0, 0, i);
@@ -254,10 +258,10 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
         vt_static_for<4>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             conv_epilogue<T, BM, BN, WM, WN>(p, acc[c], smem, QuadRows<TW>{img, y0, x0, c >> 1, c & 1, p.H, p.W}, n0, split,
-                                             tile_n * p.tiles_m + tile_m);
+                                             tile_n * p.tiles_m + tile_m, etab);
         });
     } else {
         conv_epilogue<T, BM, BN, WM, WN>(p, acc[0], smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split,
-                                         tile_n * p.tiles_m + tile_m);
+                                         tile_n * p.tiles_m + tile_m, etab);
     }
 }
