@@ -602,6 +602,59 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
         assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < (F32_TOL if dtype == torch.float32 else 8e-3)
 
 
+def test_conv_patch_persistent_equals_one_workgroup_per_tile(dev, monkeypatch):
+    """conv_patchq_kernel (csrc/conv_patch_persist.hpp): persistent workgroups walk contiguous ranges of tiles and the loader
+    prefetches across tile boundaries (the successor's first patch and taps land during the epilogue).  Same K order, same lean
+    epilogue -> the SAME BITS as one workgroup per tile (VT_PATCH_PIPE=1).  VT_PATCHW_WGS = few workgroups so that small
+    convolutions have more tiles than workgroups: ranges that cross into the next channel tile (tables reloaded), uneven ranges,
+    several chunks, two sources, ragged edges, a batch, residual + LeakyReLU, the fused ToRGB (its LDS exchange lives behind the
+    patch here), 128- and 64-channel tiles."""
+    dtype = torch.bfloat16
+    g = np.random.default_rng(43)
+    for N, c0, c1, H, W, cout, hint, wgs, rgb in ((2, 192, 0, 21, 35, 136, P + 256128, 3, False),
+                                                  (1, 64, 128, 33, 40, 128, P + 256128, 4, True),
+                                                  (3, 128, 0, 17, 31, 72, P + 256064, 5, False),
+                                                  (1, 128, 0, 40, 50, 64, P + 256064, 2, True)):
+        cin = c0 + c1
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xa = K.nchw_to_nhwc(T(x[:, :c0], dev), dtype)
+        xb = K.nchw_to_nhwc(T(x[:, c0:], dev), dtype) if c1 else None
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        ldo = cout
+        r = K.nchw_to_nhwc(T(g.standard_normal((N, cout, H, W)).astype(np.float32), dev), dtype, ld_out=ldo)
+        rgbw = K.pack_conv_weight(T((g.standard_normal((3, cout, 1, 1)) / 8).astype(np.float32), dev), out_dtype=dtype)
+        skip = T(g.standard_normal((N, 3, H, W)).astype(np.float32), dev)
+        rgbb = T(g.standard_normal(3).astype(np.float32), dev)
+
+        def run():
+            out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
+            rgb_out = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
+            kw = dict(src1=xb, c1=c1, ld1=c1) if c1 else {}
+            if rgb:
+                kw.update(rgb_weight=rgbw, rgb_bias=rgbb, rgb_resid=skip, rgb_out=rgb_out)
+            else:
+                kw.update(resid=r, ld_res=ldo, beta=0.25)
+            K.conv2d(src0=xa, c0=c0, ld0=c0, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, alpha=0.5, out=out, ld_out=ldo, dtype=K.dt_code(dtype),
+                     tile_hint=hint, **kw)
+            return out, rgb_out
+        monkeypatch.setenv("VT_PATCHW_WGS", str(wgs))
+        got, got_rgb = run()
+        monkeypatch.setenv("VT_PATCH_PIPE", "1")
+        ref, ref_rgb = run()
+        monkeypatch.delenv("VT_PATCH_PIPE")
+        monkeypatch.delenv("VT_PATCHW_WGS")
+        assert torch.equal(got, ref) and torch.equal(got_rgb, ref_rgb), (N, c0, c1, H, W, cout, hint, wgs)
+        xq = torch.cat([xa] + ([xb] if c1 else []), dim=3).float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        want = O.leaky_relu(O.conv2d(xq, wq, b, 1, 1, 1), 0.2) * np.float32(2 ** 0.5) * 0.5
+        if not rgb:
+            want = want + 0.25 * r.float().cpu().permute(0, 3, 1, 2).numpy()
+        assert rel_err(got.float().cpu().permute(0, 3, 1, 2).numpy(), want) < 8e-3
+
+
 def test_conv_patch_weights_resident_equals_pipelined(dev, monkeypatch):
     """conv_patchw_kernel (csrc/conv_patch_resident.hpp): single-chunk layers (Cin = 64 bf16) on 256 x 64 tiles with all 9 taps
     of the weights resident in LDS and persistent workgroups that walk tiles with the next patch in flight.  Same K order as

@@ -517,10 +517,15 @@ __device__ __forceinline__ void epi_tables(const ConvArgs& p, int nbase, int q, 
 // FOUR CONSECUTIVE OUTPUT CHANNELS (4q..4q+3) of ONE pixel (l15): bias, activation, residual and
 // the store are done in registers -- 8-byte bf16 / 16-byte fp32 vectors per lane, no LDS staging
 // pass, no barriers.  (The LDS-staged epilogue this replaces cost 12 us of a 34 us launch.)
-template <typename T, int BM, int BN, int WM, int WN, typename RowMap>
+// EPI = 1: ONLY the lean path is compiled in (the host checked conv_lean(): see the lean path below, no split-K).  The general
+// epilogue is 20 000+ lines of ISA per 64 x 64 wave tile; with it in the kernel the waves of a workgroup fetch their way
+// through ~10 KB of cold code once per tile: the arithmetic of the lean path measured 4.5-6 us per workgroup, four times
+// its instruction count (profiles/r04_epilogue.txt).
+template <typename T, int BM, int BN, int WM, int WN, int EPI = 0, typename RowMap>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               unsigned char* smem, const RowMap rowmap, int n0, int split,
                                               int tile_id, const EpiTables<BN / WN / 16>& tab) {
+    static_assert(EPI == 0 || (BN / WN / 16) % 2 == 0, "the lean path finishes fragment pairs");
     // tab: the lane's bias / slope / gain tables (epi_tables) -- fetched by the caller before its K loop where it can afford
     // the registers, else by the overload below right here
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -530,7 +535,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, l15 = lane & 15;
     // ---- split-K: every slice writes its raw fp32 accumulators to the workspace ----------
-    if (p.splitk > 1) {
+    if (EPI == 0 && p.splitk > 1) {
         const int64_t slab = (int64_t)p.M * p.ldp;
         float* part = p.partial + (int64_t)split * slab;
 #pragma unroll
@@ -613,8 +618,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     // element).  Fetched inside store_out8_bf16 each was a round trip behind the acknowledgement of the store before it.
     constexpr int NPAIR = (TN + BS - 1) / BS;
     u128 rpre[NPAIR][TM];
-    const bool rvec = BS == 2 && sizeof(T) == 2 && p.resid && p.phases == 1 && p.out_layout == VT_OUT_NHWC && !p.out_f32 &&
-                      p.vec_store && !((p.ld_out | p.ld_res) & 7);
+    const bool rvec = EPI == 1 ? (sizeof(T) == 2 && p.resid != nullptr)
+                               : (BS == 2 && sizeof(T) == 2 && p.resid && p.phases == 1 && p.out_layout == VT_OUT_NHWC && !p.out_f32 &&
+                                  p.vec_store && !((p.ld_out | p.ld_res) & 7));
     if (rvec) {
 #pragma unroll
         for (int b0 = 0; b0 < TN; b0 += BS) {
@@ -636,9 +642,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
     bool lean = false;
     if constexpr (BS == 2) {
         constexpr bool H = sizeof(T) == 2;   // bf16 rows (one 16-byte store per 8 channels) or fp32 rows (two)
-        lean = (p.act == VT_ACT_NONE || p.act == VT_ACT_LRELU) && p.phases == 1 && p.out_layout == VT_OUT_NHWC &&
-               (H ? !p.out_f32 : p.out_f32 != 0) && p.vec_store && !p.post_relu && !(p.coutT & 7) &&
-               (H ? (!p.resid || rvec) && !(p.ld_out & 7) : !(p.ld_out & 3) && (!p.resid || !(p.ld_res & 3)));
+        lean = EPI == 1 ||   // (the same predicate on the host: conv_lean())
+               ((p.act == VT_ACT_NONE || p.act == VT_ACT_LRELU) && p.phases == 1 && p.out_layout == VT_OUT_NHWC &&
+                (H ? !p.out_f32 : p.out_f32 != 0) && p.vec_store && !p.post_relu && !(p.coutT & 7) &&
+                (H ? (!p.resid || rvec) && !(p.ld_out & 7) : !(p.ld_out & 3) && (!p.resid || !(p.ld_res & 3))));
         if (lean) {
             const bool lrelu = p.act == VT_ACT_LRELU;
 #pragma unroll
@@ -695,7 +702,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
             }
         }
     }
-    if (!lean) {
+    if (EPI == 0 && !lean) {
 #pragma unroll
     for (int b0 = 0; b0 < TN; b0 += BS) {
         int nh[BS];
@@ -1598,6 +1605,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
 #include "conv_patch_resident.hpp"
+#include "conv_patch_persist.hpp"
 
 // slab column of the 4-channel group starting at channel n (n % 4 == 0): identity, or the
 // fragment order the slices wrote (tile row 32j + 16h + 4q + r  <-  channel 32j + 8q + 4h + r)
@@ -2262,6 +2270,33 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
+// the convolutions whose epilogue is the lean path of conv_epilogue (same predicate as there): kernels instantiated with EPI = 1
+// carry nothing else
+template <typename T>
+static bool conv_lean(const ConvArgs& a) {
+    constexpr bool H = sizeof(T) == 2;
+    return (a.act == VT_ACT_NONE || a.act == VT_ACT_LRELU) && a.phases == 1 && a.out_layout == VT_OUT_NHWC &&
+           (H ? !a.out_f32 : a.out_f32 != 0) && a.vec_store && !a.post_relu && !(a.coutT & 7) &&
+           (H ? (!a.resid || !(a.ld_res & 7)) && !(a.ld_out & 7) : !(a.ld_out & 3) && (!a.resid || !(a.ld_res & 3)));
+}
+
+// persistent form of the pipelined patch tiles (conv_patch_persist.hpp): launches of more tiles than CUs, whole K, lean epilogue
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4>
+int launch_patchq(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    ConvArgs args = a;
+    args.slab_perm = 1;
+    args.tiles_n = vt_cdiv(a.coutT, BN);
+    args.tiles_m = a.N * vt_cdiv(a.Ho, TH) * vt_cdiv(a.Wo, 16);
+    args.kps = a.cin / (8 * (16 / (int)sizeof(T)));
+    args.splitk = 1;
+    split_mode(args);
+    const int64_t units = (int64_t)args.tiles_m * args.tiles_n;
+    const int wgs = units < patchw_wgs() ? (int)units : patchw_wgs();
+    auto k = conv_patchq_kernel<T, TH, BN, WM, WN, NSTB>;
+    VT_LAUNCH(k, dim3((unsigned)wgs), dim3(WM * WN * 64), stream, args, g);
+    return vt_check_launch("vt_conv2d(patch, pipelined, persistent)");
+}
+
 template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0>
 int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -2279,8 +2314,18 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         return VT_ERR_ARG;
     }
     if (args.phase != 2) {
-        auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP>;
-        VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        bool done = false;
+        if constexpr (UP == 0 && (BN / WN / 16) % 2 == 0) {
+            if (args.splitk == 1 && conv_lean<T>(args)) {   // the lean-epilogue instance: a fifth of the code
+                auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 1>;
+                VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+                done = true;
+            }
+        }
+        if (!done) {
+            auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 0>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        }
     }
     int rc = vt_check_launch("vt_conv2d(patch, pipelined)");
     if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
@@ -2469,6 +2514,16 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                     a.splitk <= 1 &&
                     (int64_t)(batch_exact() ? 1 : a.N) * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) >= 2 * patchw_wgs())
                     return launch_patchw<T, 16, 64>(a, g, stream);
+            }
+            // more tiles than CUs, whole K, lean epilogue: persistent workgroups, the pipeline runs across tile boundaries
+            // (VT_PATCH_PIPE=1: one workgroup per tile, A/B).  VT_BATCH_EXACT or not: the same bits either way.
+            if constexpr (sizeof(T) == 2) {
+                if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && (t.bn == 128 || t.bn == 64) && a.splitk <= 1 &&
+                    conv_lean<T>(a) &&
+                    (int64_t)a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, t.bn) > patchw_wgs()) {
+                    if (t.bn == 128) return launch_patchq<T, 16, 128, 4, 2, 4>(a, g, stream);
+                    return launch_patchq<T, 16, 64, 4, 2, 4>(a, g, stream);
+                }
             }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);

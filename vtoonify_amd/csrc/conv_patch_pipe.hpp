@@ -57,7 +57,7 @@ struct QuadRows {
     }
 };
 
-template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0>
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0, int EPI = 0>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int TW = 16;
@@ -261,7 +261,7 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
                                              tile_n * p.tiles_m + tile_m, etab);
         });
     } else {
-        conv_epilogue<T, BM, BN, WM, WN>(p, acc[0], smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split,
-                                         tile_n * p.tiles_m + tile_m, etab);
+        conv_epilogue<T, BM, BN, WM, WN, EPI>(p, acc[0], smem, PatchRows<TW>{img, y0, x0, p.Ho, p.Wo}, n0, split,
+                                              tile_n * p.tiles_m + tile_m, etab);
     }
 }
