@@ -102,7 +102,9 @@ def test_hot_kernels_do_not_spill():
     import kernel_resources
     table = kernel_resources.kernel_table()
     assert len(table) > 100
-    capped = ("conv3x3_c64_kernel", "conv_upblur_kernel")
+    # (conv_patchq_kernel<256x128>: 14 loop-invariant values written in the prologue and read back in the epilogue -- none inside
+    # the K loop -- because the persistent tile loop keeps the epilogue's operands and the loader's offsets alive together)
+    capped = ("conv_upblur_kernel", "conv_patchq_kernel")
     bad = {k: v["scratch"] for k, v in table.items()
            if v["scratch"] > (128 if any(c in k for c in capped) else 0)}
     assert not bad, bad
