@@ -83,8 +83,11 @@ def pmc_traffic(kernel_class: str):
         else:
             lead = f"{name}<{tt}, {bm // 16 if name == 'conv_patch_kernel' else bm}, {bn},"
         hit = [v for k, v in table.items() if k.startswith(lead)]
-        if name == "conv_patch_kernel":   # ... and its software-pipelined form (csrc/conv_patch_pipe.hpp), the same plan kind
-            hit += [v for k, v in table.items() if k.startswith(lead.replace("conv_patch_kernel", "conv_patchp_kernel"))]
+        if name == "conv_patch_kernel":   # ... and the other kernels of the same plan kind: software-pipelined
+            # (csrc/conv_patch_pipe.hpp), persistent (conv_patch_persist.hpp), weights resident (conv_patch_resident.hpp)
+            for alt in ("conv_patchp_kernel", "conv_patchq_kernel"):
+                hit += [v for k, v in table.items() if k.startswith(lead.replace("conv_patch_kernel", alt))]
+            hit += [v for k, v in table.items() if k.startswith(f"conv_patchw_kernel<{tt}, {bm // 16}, {bn}>")]
     n = sum(v["launches_sampled"] for v in hit)
     if not n:
         return None, None

@@ -816,6 +816,13 @@ class VToonifyEngine:
             plan = self._build_plan(B, H, W, bool(shared_style), has_res)
             self._plans[key] = plan
             while len(self._plans) > self.max_plans:   # least recently used plan: its buffers and graph are dropped
+                # ... but its last replay may still be running on its lane's stream, and the buffers go back to the caching
+                # allocator, which only knows the stream that allocated them: the next plan built on another stream could be
+                # handed memory that is still being written (seen once as a one-LSB difference in
+                # test_video_driver_matches_frame_by_frame, whose shard phase is the 13th plan of one engine).  Evictions
+                # are rare: drain the device first.
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
                 self._plans.popitem(last=False)
         else:
             self._plans.move_to_end(key)
