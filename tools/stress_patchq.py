@@ -37,11 +37,13 @@ for N, c0, c1, H, W, cout, hint, rgb in cases:
             kw.update(resid=r, ld_res=cout, beta=0.25)
         K.conv2d(src0=xa, c0=c0, ld0=c0, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=1, bias=b,
                  act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dt), tile_hint=hint, **kw)
-    os.environ["VT_PATCH_PIPE"] = "1"
+    selfref = len(sys.argv) > 2 and sys.argv[2] == "self"   # reference = the same kernel, run once alone (determinism only)
+    if not selfref:
+        os.environ["VT_PATCH_PIPE"] = "1"
     ref, ref_rgb = torch.zeros(N, H, W, cout, dtype=dt, device=dev), torch.zeros(N, 3, H, W, device=dev)
     run(ref, ref_rgb)
     torch.cuda.synchronize()
-    del os.environ["VT_PATCH_PIPE"]
+    os.environ.pop("VT_PATCH_PIPE", None)
     outs = [(torch.zeros_like(ref), torch.zeros_like(ref_rgb)) for _ in streams]
     bad = 0
     for it in range(iters):
