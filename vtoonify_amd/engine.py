@@ -818,9 +818,7 @@ class VToonifyEngine:
             while len(self._plans) > self.max_plans:   # least recently used plan: its buffers and graph are dropped
                 # ... but its last replay may still be running on its lane's stream, and the buffers go back to the caching
                 # allocator, which only knows the stream that allocated them: the next plan built on another stream could be
-                # handed memory that is still being written (seen once as a one-LSB difference in
-                # test_video_driver_matches_frame_by_frame, whose shard phase is the 13th plan of one engine).  Evictions
-                # are rare: drain the device first.
+                # handed memory that is still being written.  Evictions are rare: drain the device first.
                 if self.device.type == "cuda":
                     torch.cuda.synchronize(self.device)
                 self._plans.popitem(last=False)
@@ -876,8 +874,9 @@ class VToonifyEngine:
             cacheable = self.cache_styles and own
             plan.style_ref = style_arg if cacheable else None
             plan.style_key = skey + (d_s,) if cacheable else None
-        # a hipGraph is captured the SECOND time a (shape, lane) is seen: a one-off crop size runs eager launches and
-        # costs no warm-up frame, device sync and capture
+        # By default (VT_GRAPH_FIRST=1) the hipGraph of a (shape, lane) is captured on its FIRST call: a video or a benchmark
+        # replays it from the second frame on.  VT_GRAPH_FIRST=0 defers the capture to the second call, so that a one-off crop
+        # size runs eager launches and pays no warm-up frame, device sync and capture (ADVICE r2 -- opt-in, for image mode)
         seen = self._shape_seen[key] = self._shape_seen.get(key, 0) + 1
         if len(self._shape_seen) > 4096:
             self._shape_seen.clear()
