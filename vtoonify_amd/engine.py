@@ -673,6 +673,11 @@ class VToonifyEngine:
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
+                # ... except on the 128-channel patch tiles in bf16: there the fused ToRGB runs on the general epilogue (DESIGN.md
+                # 4.1m), and the plain conv on the lean / persistent kernels + one thin ToRGB launch over the stored activation is
+                # faster (the 128 -> 128 conv at 256^2: 126 us fused against 80 + 18)
+                if fuse_rgb and self.dt == K.VT_BF16 and tile // 100000000 == 1 and tile % 1000 == 128:
+                    fuse_rgb = False
                 # the LAST level's activation feeds nothing but its ToRGB: with the fused epilogue on the persistent 32 -> 32
                 # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only)
                 rgb_only = fuse_rgb and lvl == 4 and tile // 100000000 == 3
