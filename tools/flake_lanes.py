@@ -15,6 +15,9 @@ from vtoonify_amd.engine import VToonifyEngine  # noqa: E402
 bb, B, H, W, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 use_graph = (sys.argv[6] != "eager") if len(sys.argv) > 6 else True
 dev = torch.device("cuda:0")
+if os.environ.get("FLAKE_LIB"):   # another build of the library (experiments)
+    from vtoonify_amd import _lib
+    _lib.use_library(os.environ["FLAKE_LIB"])
 backbone = "toonify" if bb == "T" else "dualstylegan"
 from conftest import load_keys  # noqa: E402
 sd = synth.synth_state_dict(load_keys(bb), 0)
