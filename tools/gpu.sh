@@ -10,6 +10,7 @@
 #   prof         rocprofv3 --kernel-trace --stats of the bench command, one and three frames in flight
 #   pmc          rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) over the eager single-stream command
 #   smoke        __graft_entry__.smoke()
+#   stress       two engine lanes / the video driver in steady state against serial results (tools/flake_lanes.py, flake_video.py)
 #   conv ARGS    tools/conv_bench.py ARGS   (quote ARGS as one word, e.g. "--stream --only res --batch 4")
 #   op           tools/op_bench.py bf16 + fp32
 #   sh CMD       arbitrary command (one word), e.g. "bash tools/ab.sh adain" (the A/B experiments of round 3)
@@ -59,6 +60,9 @@ for k,v in sorted(d.items(), key=lambda kv:-kv[1].get('sq_valu_mfma_busy_cycles_
 t=json.load(open('$O/pmc_traffic_$TAG.json'))['kernels']
 for k,v in sorted(t.items(), key=lambda kv:-kv[1]['hbm_bytes_per_launch']*kv[1]['launches_sampled'])[:8]: print(k[:70], round(v['hbm_bytes_per_launch']/1e6,2),'MB/launch', v['launches_sampled'])
 " ;;
+    stress)
+      ( for a in "D 2 64 96 400" "D 4 256 256 100" "T 2 64 96 300" "D 3 72 104 200"; do timeout 300 python tools/flake_lanes.py $a graph 2>&1 | tail -1; done
+        timeout 300 python tools/flake_video.py 20 only22 2>&1 | tail -1 ) > $O/stress_$TAG.txt 2>&1; cat $O/stress_$TAG.txt ;;
     smoke) timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> $O/smoke_$TAG.log; tail -3 $O/smoke_$TAG.log ;;
     conv) A=$1; shift
       timeout 300 python tools/conv_bench.py $A > $O/conv_${TAG}_$n.txt 2>&1; echo "# conv_bench $A" >> $O/conv_${TAG}_$n.txt; cat $O/conv_${TAG}_$n.txt | grep -v amdgpu.ids ;;
