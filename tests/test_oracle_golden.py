@@ -24,7 +24,7 @@ def backend(request):
     O.set_backend(old)
 
 
-def test_upfirdn2d_all_cases():
+def test_upfirdn2d_all_cases(backend):   # (both back-ends: the torch one is what cpu_baseline and every full-size comparison run)
     d, meta = load_golden("op_upfirdn2d.npz")
     assert len(meta) >= 12
     for m in meta:
@@ -40,7 +40,7 @@ def test_upfirdn2d_all_cases():
             assert rel_err(y, ref) < 1e-6, n
 
 
-def test_fused_leaky_relu_bit_exact():
+def test_fused_leaky_relu_bit_exact(backend):
     d, meta = load_golden("op_fused_act.npz")
     for m in meta:
         n = m["name"]

@@ -80,5 +80,38 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return out
 
 
+def build_variant(tag: str, defines, extra_flags=(), sources=("conv_igemm.hip",), verbose: bool = True) -> str:
+    """An EXPERIMENT build of the library (tools/flake_diag.py): `sources` recompiled with -D<defines> /
+    `extra_flags` into build/<tag>/, linked with the product's other objects into lib/libvtoonify_amd_<tag>.so.  The product
+    never loads such a file; tools select it with FLAKE_LIB / _lib.use_library()."""
+    build(verbose=verbose)   # the product objects the variant links against
+    hipcc = hipcc_path()
+    objdir = os.path.join(HERE, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+             "-ffp-contract=off"] + [f"-D{d}" for d in defines] + list(extra_flags)
+    objs = []
+    for s in SOURCES:
+        if s in sources:
+            obj = os.path.join(objdir, s.replace(".hip", ".o"))
+            cmd = [hipcc, "-x", "hip"] + flags + ["-c", os.path.join(CSRC, s), "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        else:
+            obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        objs.append(obj)
+    out = os.path.join(LIBDIR, f"libvtoonify_amd_{tag}.so")
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs, check=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:   # python -m vtoonify_amd.build --variant TAG [-DNAME=V ...] [-- extra hipcc flags]
+        i = sys.argv.index("--variant")
+        rest = sys.argv[i + 2:]
+        extra = rest[rest.index("--") + 1:] if "--" in rest else []
+        rest = rest[:rest.index("--")] if "--" in rest else rest
+        print(build_variant(sys.argv[i + 1], [a[2:] for a in rest if a.startswith("-D")], extra))
+    else:
+        print(build(force="--force" in sys.argv))

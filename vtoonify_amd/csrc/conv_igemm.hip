@@ -646,11 +646,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                ((p.act == VT_ACT_NONE || p.act == VT_ACT_LRELU) && p.phases == 1 && p.out_layout == VT_OUT_NHWC &&
                 (H ? !p.out_f32 : p.out_f32 != 0) && p.vec_store && !p.post_relu && !(p.coutT & 7) &&
                 (H ? (!p.resid || rvec) && !(p.ld_out & 7) : !(p.ld_out & 3) && (!p.resid || !(p.ld_res & 3))));
-        // (not with the fused ToRGB: with it the lean path gave, once in ~10 frames and only while a second lane was running
-        // on the GPU, one 16-pixel fragment row of the IMAGE wrong in channel 0 -- tools/flake_lanes.py, D 2 x 64 x 96, the plan
-        // buffer `rgb3`; the activation was always right and the arithmetic is the general path's line for line.  The cause was
-        // not found in the time there was; the general path has run 2 000 such steps clean.  DESIGN.md 4.1m)
-        if (EPI == 0 && rgbf) lean = false;   // (EPI = 1 instances are never launched with it: conv_lean())
+        // (with the fused ToRGB too -- round 4 kept those convs on the general path after a wrong-image-row defect; DESIGN.md 4.1n
+        // has the cause and what ships instead)
         if (lean) {
             const bool lrelu = p.act == VT_ACT_LRELU;
 #pragma unroll
@@ -677,9 +674,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j)
+                            for (int j = 0; j < 3; ++j) {
+#if VT_EXP & 1   // the round-4 form (SLP packs it into v_pk_mul_f32 / v_pk_add_f32): tools/flake_diag.py, DESIGN.md 4.1n
                                 rp[a][j] += (f[4 * h] * wq[h][j][0] + f[4 * h + 1] * wq[h][j][1]) +
                                             (f[4 * h + 2] * wq[h][j][2] + f[4 * h + 3] * wq[h][j][3]);
+#else
+                                const float s01 = vt_unpaired(vt_unpaired(f[4 * h] * wq[h][j][0]) + vt_unpaired(f[4 * h + 1] * wq[h][j][1]));
+                                const float s23 = vt_unpaired(vt_unpaired(f[4 * h + 2] * wq[h][j][2]) + vt_unpaired(f[4 * h + 3] * wq[h][j][3]));
+                                rp[a][j] = vt_unpaired(rp[a][j] + vt_unpaired(s01 + s23));
+#endif
+                            }
                     }
                     const bool live = m >= 0 && nn + 8 <= p.coutT;
                     if constexpr (H) {
@@ -774,7 +778,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) rsd[a][j] = p.rgb_resid[(roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo];
+            for (int j = 0; j < 3; ++j) {
+#if (VT_EXP & 2) && !defined(VT_EMU)
+                rsd[a][j] = __hip_atomic_load(p.rgb_resid + (roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+                rsd[a][j] = p.rgb_resid[(roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo];
+#endif
+            }
     } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a) rsd[a][0] = rsd[a][1] = rsd[a][2] = 0.0f;
@@ -2280,7 +2291,6 @@ int launch_patch(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
 template <typename T>
 static bool conv_lean(const ConvArgs& a) {
     constexpr bool H = sizeof(T) == 2;
-    if (a.rgb_w) return false;   // see conv_epilogue: the fused ToRGB stays on the general path
     return (a.act == VT_ACT_NONE || a.act == VT_ACT_LRELU) && a.phases == 1 && a.out_layout == VT_OUT_NHWC &&
            (H ? !a.out_f32 : a.out_f32 != 0) && a.vec_store && !a.post_relu && !(a.coutT & 7) &&
            (H ? (!a.resid || !(a.ld_res & 7)) && !(a.ld_out & 7) : !(a.ld_out & 3) && (!a.resid || !(a.ld_res & 3)));

@@ -81,6 +81,7 @@ class VToonifyEngine:
         self.dt = K.dt_code(dtype)
         self.x3 = bool(x3) and dtype == torch.float32
         self.dt_conv = K.VT_F32X3 if self.x3 else self.dt   # vt_conv_desc.dtype; everything else sees self.dt
+        self.precision = "bf16" if dtype == torch.bfloat16 else ("fp32x3" if self.x3 else "fp32_exact")
         self.esz = 2 if dtype == torch.bfloat16 else 4
         any_t = next(iter(state_dict.values()))
         self.device = torch.device(device) if device is not None else any_t.device

@@ -181,13 +181,16 @@ class VToonify(nn.Module):
         (INTEGRATION.md 0)."""
         super().__init__()
         env = os.environ.get("VTOONIFY_AMD_DTYPE", "fp32").lower()
-        if env not in ("fp32", "float32", "fp32_exact", "bf16", "bfloat16"):
-            raise ValueError(f"VTOONIFY_AMD_DTYPE={env!r}: expected fp32, fp32_exact or bf16")
+        if (compute_dtype is None or exact_fp32 is None) and env not in ("fp32", "float32", "fp32x3", "fp32_exact", "bf16", "bfloat16"):
+            raise ValueError(f"VTOONIFY_AMD_DTYPE={env!r}: expected fp32 (= fp32x3), fp32_exact or bf16")
         if compute_dtype is None:
             compute_dtype = torch.bfloat16 if env.startswith("b") else torch.float32
         if exact_fp32 is None:
             exact_fp32 = env == "fp32_exact"
         self.exact_fp32 = bool(exact_fp32)
+        # the arithmetic in force, by name: "fp32x3" (fp32 tensors, conv products as three bf16 MFMAs: the default), "fp32_exact"
+        # (exact-fp32 matrix instructions, the bisection reference) or "bf16" -- what a log line / bench.py should print
+        self.precision = "bf16" if compute_dtype == torch.bfloat16 else ("fp32_exact" if exact_fp32 else "fp32x3")
         self.backbone = backbone
         self.in_size = in_size
         self.style_channels = style_channels
@@ -251,17 +254,30 @@ class VToonify(nn.Module):
         """Fingerprint of EVERY parameter and buffer (storage address, in-place version counter): a `.to()`, a re-assignment
         of a submodule (`model.generator = ...`) and an in-place edit of any parameter (`p.mul_(...)`, `p.copy_(...)`) all
         change it and drop the packed weights.  Only edits through `.data` escape the version counters -- those need
-        invalidate().  Walking the module tree costs ~2 ms (per call that was most of a 3.5 ms step), so the
-        list of tensors is cached: every call reads the ~400 cached tensors' address / version (0.1 ms); the tree is walked
-        again when this module's own attributes change (__setattr__, _apply, load_state_dict bump an epoch) and on every
-        64th call (a submodule swapped deep inside the tree is noticed within 64 calls; invalidate() is immediate)."""
-        self._probe_calls = getattr(self, "_probe_calls", 0) + 1
-        ts = getattr(self, "_probe_tensors", None)
-        if ts is None or self._probe_epoch_seen != self._probe_epoch or self._probe_calls % 64 == 0:
-            ts = list(self.parameters()) + list(self.buffers())
-            object.__setattr__(self, "_probe_tensors", ts)
+        invalidate().  Walking the module tree costs ~2 ms (per call that was most of a 3.5 ms step), so the walk
+        is cached as (owning dict, name, object) triples of every parameter, buffer and child module; every call checks that
+        each dict still holds the SAME object under that name (~550 dict lookups, 0.1 ms) and reads the tensors' address /
+        version.  A replacement at any depth -- `model.generator.convs[i] = ...`, `sub.load_state_dict(..., assign=True)`,
+        `register_parameter` on a child, `child.to(...)` with parameters overwritten on conversion -- fails an identity check
+        on the NEXT call and the tree is walked again (the 64-call window is gone)."""
+        trip = getattr(self, "_probe_triples", None)
+        fresh = trip is None or self._probe_epoch_seen != self._probe_epoch
+        if not fresh:
+            for d, n, o in trip:
+                if d.get(n) is not o:
+                    fresh = True
+                    break
+        if fresh:
+            trip = []
+            for m in self.modules():
+                trip += [(m._modules, n, c) for n, c in m._modules.items()]
+                trip += [(m._parameters, n, t) for n, t in m._parameters.items()]
+                trip += [(m._buffers, n, t) for n, t in m._buffers.items()]
+            object.__setattr__(self, "_probe_triples", trip)
+            object.__setattr__(self, "_probe_tensors", [o for _, _, o in trip if isinstance(o, torch.Tensor)])
             object.__setattr__(self, "_probe_epoch_seen", self._probe_epoch)
-        h = len(ts)
+        ts = self._probe_tensors
+        h = len(trip)
         for t in ts:
             h = (h * 1000003 + t.data_ptr() * 31 + t._version) & 0xFFFFFFFFFFFFFFF
         return h
