@@ -2,8 +2,9 @@
 # Round 5, experiment A: the round-4 wrong-image-row defect of the lean epilogue with the fused ToRGB.
 #   gpurun --timeout 900 -- 'bash tools/exp_r05a.sh'
 # Arms (tools/flake_diag.py, D 2 x 64 x 96, two lanes in steady state, every wrong step explained from precomputed references):
-#   exp1 = the round-4 form (library built with -DVT_EXP=1), graph / eager / not-in-place image; exp3 = + system-scope skip loads;
-#   product = the shipped form.
+#   exp1 = the round-4 form (SLP-packed ToRGB sums: `python -m vtoonify_amd.build --variant exp1 -- -fslp-vectorize`; at commit
+#   af79b78, where these arms ran, it was -DVT_EXP=1), graph / eager / not-in-place image; exp3 = + system-scope skip loads (VT_EXP=3
+#   at af79b78; gone since); product = the shipped form.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out; L=$GRAFT_REPO_ROOT/vtoonify_amd/lib
 run() {  # tag lib steps mode [env...]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """EXPERIMENT build with the device ISA patched by hand: csrc/conv_igemm.hip is compiled to gfx950 assembly
-with -DVT_EXP=1 (the round-4 form of the lean fused-ToRGB epilogue), a rule edits the assembly, and the result is assembled,
+with -fslp-vectorize (round 4's packed code: the defect's reproducer), a rule edits the assembly, and the result is assembled,
 linked, bundled and embedded into a host object exactly as hipcc does (`hipcc -###`), then linked with the product's other
 objects into vtoonify_amd/lib/libvtoonify_amd_<TAG>.so.
 
@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 CSRC = os.path.join(REPO, "vtoonify_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-ffp-contract=off",
-         "-DVT_EXP=1"]
+         "-fslp-vectorize"]   # (the experiments of profiles/r05_torgb_defect.txt ran at commit af79b78, where this was -DVT_EXP=1)
 _REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
 

@@ -21,6 +21,13 @@ LIBNAME = "libvtoonify_amd.so"
 SOURCES = ["capi.hip", "fused_bias_act.hip", "upfirdn2d.hip", "style_ops.hip", "conv_igemm.hip",
            "norm_glue.hip", "frame_io.hip", "parsing_glue.hip", "raft_corr.hip", "flow_ops.hip"]
 ARCH = "gfx950"
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs neighbouring fp32 operations into v_pk_{mul,add,fma}_f32 with lane selects;
+# the form `op_sel:[0,1]` (low result reads the HIGH register of src1) returns src1.hi as ZERO on gfx950 in ~1 % of executions
+# while another wave issues v_mfma_f32_16x16x32_bf16 on the same SIMD -- the wrong image rows of round 4 (DESIGN.md 4.1n,
+# tools/probe/pk_war_probe.hip is the minimal reproducer).  Without the pass the library holds 70 packed fp32 instructions
+# (34 000 with it), none with op_sel; tests/test_isa_lint.py pins that.  Frame rate: unchanged (profiles/r05_torgb_defect.txt).
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-ffp-contract=off",
+         "-fno-slp-vectorize"]
 
 
 def hipcc_path() -> str:
@@ -52,8 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-             "-Wno-unused-result", "-ffp-contract=off"]
+    flags = list(FLAGS)
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -82,14 +88,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 def build_variant(tag: str, defines, extra_flags=(), sources=("conv_igemm.hip",), verbose: bool = True) -> str:
     """An EXPERIMENT build of the library (tools/flake_diag.py): `sources` recompiled with -D<defines> /
-    `extra_flags` into build/<tag>/, linked with the product's other objects into lib/libvtoonify_amd_<tag>.so.  The product
-    never loads such a file; tools select it with FLAKE_LIB / _lib.use_library()."""
+    `extra_flags` (appended to the product's flags: `-fslp-vectorize` gives back round 4's packed code, the defect's reproducer)
+    into build/<tag>/, linked with the product's other objects into lib/libvtoonify_amd_<tag>.so.  The product never loads
+    such a file; tools select it with FLAKE_LIB / _lib.use_library()."""
     build(verbose=verbose)   # the product objects the variant links against
     hipcc = hipcc_path()
     objdir = os.path.join(HERE, "build", tag)
     os.makedirs(objdir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-             "-ffp-contract=off"] + [f"-D{d}" for d in defines] + list(extra_flags)
+    flags = list(FLAGS) + [f"-D{d}" for d in defines] + list(extra_flags)
     objs = []
     for s in SOURCES:
         if s in sources:

@@ -646,10 +646,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                ((p.act == VT_ACT_NONE || p.act == VT_ACT_LRELU) && p.phases == 1 && p.out_layout == VT_OUT_NHWC &&
                 (H ? !p.out_f32 : p.out_f32 != 0) && p.vec_store && !p.post_relu && !(p.coutT & 7) &&
                 (H ? (!p.resid || rvec) && !(p.ld_out & 7) : !(p.ld_out & 3) && (!p.resid || !(p.ld_res & 3))));
-        // (with the fused ToRGB too -- round 4 kept those convs on the general path after a wrong-image-row defect; DESIGN.md 4.1n
-        // has the cause and what ships instead)
+        // (with the fused ToRGB too.  Round 4 kept those convs on the general path after a wrong-image-row defect; the cause was
+        // not this code but what hipcc's SLP vectoriser made of the partial sums below -- `v_pk_mul_f32 / v_pk_add_f32 ...
+        // op_sel:[0,1]`, whose low half reads src1's high register as ZERO on gfx950 while another wave's MFMA shares the SIMD
+        // (tools/probe/pk_war_probe.hip).  The library is built with -fno-slp-vectorize and tests/test_isa_lint.py forbids
+        // the instruction form)
         if (lean) {
             const bool lrelu = p.act == VT_ACT_LRELU;
+            // bf16: the fused ToRGB on the matrix cores.  Under PERM the 8 values a lane finishes for a fragment pair are 8
+            // CONSECUTIVE channels of one pixel -- packed to bf16 (the 16 bytes the store writes) they are exactly the pixel
+            // operand of v_mfma_f32_16x16x32_bf16 for this pair's 32 channels, and with the ToRGB weights as the other operand
+            // (row j < 3 of the fragment = image plane j, rows 3..15 zero) ONE instruction per 16-pixel fragment row and pair
+            // replaces 48 multiply-adds per lane, the weight unpacking and the 24 cross-lane shuffles of the sums below: lanes
+            // q == 0 end up with the three plane values of their pixel.  The products are those of the un-fused ToRGB launch
+            // (bf16 activations as stored x bf16 weights, fp32 accumulate); round 4's lean fused epilogue cost +20 us on the
+            // 128 -> 128 conv at 256^2 in vector instructions (profiles/r05_torgb_fused.txt).
+            // The weight operand of fragment row a carries its three rows at 4a .. 4a + 2, so the products of the TM <= 4
+            // fragment rows land in DIFFERENT rows of one accumulator: lane (q, l15) ends up with the three plane values of
+            // pixel l15 of fragment row q -- the reduce-scatter the vector form needed 9 shuffles per plane triple for.
+            constexpr bool RGB_MMA = sizeof(T) == 2;
+            static_assert(!RGB_MMA || TM <= 4, "four fragment rows share the 16 rows of the ToRGB accumulator");
+            f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int b0 = 0; b0 < TN; b0 += 2) {
                 const int nn = n0 + wn * (TN * 16) + frag_channel<PERM>(b0, q);
@@ -659,7 +676,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                     bb[k] = tab.bv[b0 + (k >> 2)][k & 3];
                     se[k] = lrelu ? tab.sv[b0 + (k >> 2)][k & 3] : 1.0f;
                 }
-                if (rgbf) rgb_pair_weights<T, PERM>(p, n0 + wn * (TN * 16), b0, q, wq);
+                u128 wfrag = u128{0u, 0u, 0u, 0u};
+                if (rgbf) {
+                    if constexpr (RGB_MMA) {
+                        // weight operand: lane (q, l15) = plane l15 & 3 (row l15 of the operand of fragment row l15 >> 2), channels
+                        // nn .. nn + 7 (unconditional load at a clamped address)
+                        const bool okw = (l15 & 3) < 3 && nn + 8 <= p.coutT;
+                        const u128 wv = ld128((const bf16_t*)p.rgb_w + (okw ? (l15 & 3) * p.coutT + nn : 0));
+                        wfrag.x = okw ? wv.x : 0u, wfrag.y = okw ? wv.y : 0u, wfrag.z = okw ? wv.z : 0u, wfrag.w = okw ? wv.w : 0u;
+                    } else {
+                        rgb_pair_weights<T, PERM>(p, n0 + wn * (TN * 16), b0, q, wq);
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
@@ -671,19 +699,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                         f[k] = v * ga;
                     }
                     if (rgbf) {
+                        if constexpr (RGB_MMA) {
+                            const bool mine = (l15 >> 2) == a;
+                            u128 wa;
+                            wa.x = mine ? wfrag.x : 0u, wa.y = mine ? wfrag.y : 0u, wa.z = mine ? wfrag.z : 0u, wa.w = mine ? wfrag.w : 0u;
+                            Mma<bf16_t>::run(racc, wa, pack16<bf16_t>(f));
+                        } else {
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-#if VT_EXP & 1   // the round-4 form (SLP packs it into v_pk_mul_f32 / v_pk_add_f32): tools/flake_diag.py, DESIGN.md 4.1n
-                                rp[a][j] += (f[4 * h] * wq[h][j][0] + f[4 * h + 1] * wq[h][j][1]) +
-                                            (f[4 * h + 2] * wq[h][j][2] + f[4 * h + 3] * wq[h][j][3]);
-#else
-                                const float s01 = vt_unpaired(vt_unpaired(f[4 * h] * wq[h][j][0]) + vt_unpaired(f[4 * h + 1] * wq[h][j][1]));
-                                const float s23 = vt_unpaired(vt_unpaired(f[4 * h + 2] * wq[h][j][2]) + vt_unpaired(f[4 * h + 3] * wq[h][j][3]));
-                                rp[a][j] = vt_unpaired(rp[a][j] + vt_unpaired(s01 + s23));
-#endif
-                            }
+                                for (int j = 0; j < 3; ++j)
+                                    rp[a][j] += (f[4 * h] * wq[h][j][0] + f[4 * h + 1] * wq[h][j][1]) +
+                                                (f[4 * h + 2] * wq[h][j][2] + f[4 * h + 3] * wq[h][j][3]);
+                        }
                     }
                     const bool live = m >= 0 && nn + 8 <= p.coutT;
                     if constexpr (H) {
@@ -707,6 +735,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
                             st128(o, pack16<float>(f)), st128(o + 4, pack16<float>(f + 4));
                         }
                     }
+                }
+            }
+            if constexpr (RGB_MMA) {
+                if (rgbf) {
+                    // ---- tail of the matrix form: lane (q, l15) owns pixel l15 of fragment row q -------------------------------
+                    const int HoWo = p.Ho * p.Wo;
+                    const int m = q < TM ? rowmap(wm * (TM * 16) + q * 16 + l15) : -1;
+                    const int mc = m < 0 ? 0 : m;
+                    const int img = mc / HoWo;
+                    const int64_t off = (int64_t)img * 3 * HoWo + (mc - img * HoWo);   // (clamped: the loads stay unconditional)
+                    float rsd[3] = {0.0f, 0.0f, 0.0f}, rb[3] = {0.0f, 0.0f, 0.0f};
+                    const bool writer = wn == 0 && m >= 0;
+                    if (p.rgb_resid) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) rsd[j] = p.rgb_resid[off + (int64_t)j * HoWo];
+                    }
+                    if (p.rgb_bias) rb[0] = p.rgb_bias[0], rb[1] = p.rgb_bias[1], rb[2] = p.rgb_bias[2];
+                    float v[3] = {racc[0], racc[1], racc[2]};
+                    if (WN > 1) {   // ... summed over the WN wavefronts that split the channels (through LDS, fixed order)
+                        float* xs = reinterpret_cast<float*>(smem);
+                        __syncthreads();   // every wave is done with the tile buffers
+                        if (wn != 0) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) xs[(((wn - 1) * WM + wm) * 64 + lane) * 3 + j] = v[j];
+                        }
+                        __syncthreads();
+                        if (wn == 0) {
+                            for (int w2 = 1; w2 < WN; ++w2)
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) v[j] += xs[(((w2 - 1) * WM + wm) * 64 + lane) * 3 + j];
+                        }
+                    }
+                    if (writer) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) p.rgb_out[off + (int64_t)j * HoWo] = (v[j] + rb[j]) + rsd[j];
+                    }
+                    return;
                 }
             }
         }
@@ -779,12 +844,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-#if (VT_EXP & 2) && !defined(VT_EMU)
-                rsd[a][j] = __hip_atomic_load(p.rgb_resid + (roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_SYSTEM);
-#else
                 rsd[a][j] = p.rgb_resid[(roff[a] < 0 ? 0 : roff[a]) + (int64_t)j * HoWo];
-#endif
             }
     } else {
 #pragma unroll
@@ -1476,19 +1536,21 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     const bool rgbf = p.rgb_w != nullptr;
     // (one wave-uniform branch per table with all of its loads inside: the per-element "pointer ? load : 0" form is a
     // dependent L2 round trip per element -- 35 of them ahead of the first tile of every persistent workgroup)
-    float rwt[3][TN][4];
+    // Fused ToRGB on the matrix cores (conv_epilogue has the derivation): a lane's 8 finished values of a pixel, packed to
+    // bf16, are the pixel operand of v_mfma_f32_16x16x32_bf16 over the 32 channels; the weight operand holds plane l15 & 3 in
+    // row l15 (used for fragment row l15 >> 2), so ONE accumulator collects the four tile rows and lane (q, l15) ends with
+    // the three plane values of pixel l15 of row q.  4 registers of weights instead of 24, 4 MFMAs instead of 96 multiply-adds
+    // and 9 shuffles per tile.
     float bvr[TN][4];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bvr[b][i] = rwt[0][b][i] = rwt[1][b][i] = rwt[2][b][i] = 0.0f;
+        for (int i = 0; i < 4; ++i) bvr[b][i] = 0.0f;
+    u128 rwf = u128{0u, 0u, 0u, 0u};
     if (rgbf) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rwt[j][b][i] = to_f32(((const T*)p.rgb_w)[j * 32 + frag_channel<true>(b, q) + i]);
+        const bool okw = (l15 & 3) < 3;
+        const u128 wv = ld128((const bf16_t*)p.rgb_w + (okw ? (l15 & 3) * 32 + q * 8 : 0));
+        rwf.x = okw ? wv.x : 0u, rwf.y = okw ? wv.y : 0u, rwf.z = okw ? wv.z : 0u, rwf.w = okw ? wv.w : 0u;
     }
     if (p.bias) {
 #pragma unroll
@@ -1559,11 +1621,10 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
         // bias + LeakyReLU * gain -> bf16 NHWC (8-byte stores), optional fused ToRGB
         {
             const float ga = p.gain_alpha;
-            float rp[TM][3];
+            f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int m = rowmap(wm * (TM * 16) + a * 16 + l15);
-                float r0 = 0.f, r1 = 0.f, r2 = 0.f;
                 float f[8];   // channels 8q .. 8q+7 of this pixel: fragment 0 holds 8q..+3, fragment 1 8q+4..+7
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
@@ -1573,36 +1634,19 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
                         if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
                         f[4 * b + i] = v * ga;
                     }
-                    if (rgbf) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            r0 += f[4 * b + i] * rwt[0][b][i];
-                            r1 += f[4 * b + i] * rwt[1][b][i];
-                            r2 += f[4 * b + i] * rwt[2][b][i];
-                        }
-                    }
+                }
+                const u128 fpk = pack16<bf16_t>(f);
+                if (rgbf) {
+                    const bool mine = (l15 >> 2) == a;
+                    u128 wa;
+                    wa.x = mine ? rwf.x : 0u, wa.y = mine ? rwf.y : 0u, wa.z = mine ? rwf.z : 0u, wa.w = mine ? rwf.w : 0u;
+                    Mma<bf16_t>::run(racc, wa, fpk);
                 }
                 // one 16-byte store per lane: the four lane groups write the pixel's 64 bytes
-                if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + cg + q * 8, pack16<bf16_t>(f));
-                rp[a][0] = r0; rp[a][1] = r1; rp[a][2] = r2;
+                if (m >= 0 && !p.rgb_only) st128((bf16_t*)p.out + (int64_t)m * p.ld_out + cg + q * 8, fpk);
             }
             if (rgbf) {
-                // reduce-scatter over the four lane groups (each holds 8 of a pixel's 32 channels, for all 4 tile rows): after
-                // the exchange with lane + 32 a lane holds two rows summed over two groups, after the one with lane + 16 ONE
-                // row -- row q -- summed over all four: 9 cross-lane moves instead of 24, and every lane has a pixel to write
-                const bool hi = q >= 2, odd = (q & 1) != 0;
-                float rr[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float keep_a = hi ? rp[2][j] : rp[0][j], keep_b = hi ? rp[3][j] : rp[1][j];
-                    const float send_a = hi ? rp[0][j] : rp[2][j], send_b = hi ? rp[1][j] : rp[3][j];
-                    keep_a += __shfl_xor(send_a, 32, 64);
-                    keep_b += __shfl_xor(send_b, 32, 64);
-                    float keep = odd ? keep_b : keep_a;
-                    const float send = odd ? keep_a : keep_b;
-                    keep += __shfl_xor(send, 16, 64);
-                    rr[j] = keep;
-                }
+                const float rr[3] = {racc[0], racc[1], racc[2]};   // lane (q, l15): pixel l15 of tile row q
                 if (m_rgb >= 0) {
                     p.rgb_out[o_rgb] = rr[0] + rb0 + rsd[0];
                     p.rgb_out[o_rgb + HoWo] = rr[1] + rb1 + rsd[1];
@@ -2535,7 +2579,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // (VT_PATCH_PIPE=1: one workgroup per tile, A/B).  VT_BATCH_EXACT or not: the same bits either way.
             if constexpr (sizeof(T) == 2) {
                 if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && (t.bn == 128 || t.bn == 64) && a.splitk <= 1 &&
-                    conv_lean<T>(a) &&
+                    conv_lean<T>(a) && vt_cdiv(a.coutT, t.bn) * t.bn * 8 <= 6144 &&   // (the tables of every channel tile: 6 KB of LDS)
                     (int64_t)a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, t.bn) > patchw_wgs()) {
                     if (t.bn == 128) return launch_patchq<T, 16, 128, 4, 2, 4>(a, g, stream);
                     return launch_patchq<T, 16, 64, 4, 2, 4>(a, g, stream);

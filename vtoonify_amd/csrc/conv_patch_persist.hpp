@@ -4,8 +4,9 @@
 // conv_patchp_kernel is one workgroup per tile.  Per round of 256 workgroups it pays (profiles/r04_epilogue.txt, the 256 x 128
 // tiles, same box): ~3.6 us of prologue (address setup, the first patch and three taps of weights from a cold start, by all 256
 // CUs at once) and, at its end, the acknowledgement of the tile's 64 KB of stores before the CU can take the next workgroup -- on
-// launches of 2-4 rounds a fifth of the time.  Here a workgroup walks a contiguous range of tiles ([channel tile][pixel tile]
-// order) and the loader simply keeps going: in the last chunk of a tile the "next chunk" it prefetches (patch pieces spread over
+// launches of 2-4 rounds a fifth of the time.  Here a workgroup walks a contiguous range of tiles ([pixel tile][channel tile]
+// order since round 5: the 2-4 channel tiles of one pixel tile run back to back on ONE workgroup, so their patch is fetched
+// from HBM into one XCD's L2 once instead of once per channel tile on different XCDs) and the loader simply keeps going: in the last chunk of a tile the "next chunk" it prefetches (patch pieces spread over
 // the taps, weights D taps ahead) is chunk 0 of the NEXT tile, so when the epilogue of a tile is done its successor's first patch
 // and taps are in LDS, and the tile's stores drain under the successor's taps.  Same K order per tile, same lean epilogue: the
 // same bits as conv_patchp_kernel.  Only the lean epilogue (conv_lean()) and whole K ranges (no split) are admitted.
@@ -40,6 +41,7 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
     static_assert((D - 2) * LB + PA < 64, "vmcnt is 6 bits");
     static_assert(WN == 1 || X_OFF + BM * WN * 12 <= A_BYTES, "room for the ToRGB exchange behind the patch");
+    static_assert(A_BYTES - X_OFF >= 4096, "room for the epilogue tables of every channel tile (host: tiles_n * BN * 8 bytes)");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
 
@@ -50,7 +52,7 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const int per_img = tiles_x * tiles_y;
 
-    // units = tiles in [channel tile][pixel tile] order; workgroups in XCD-contiguous logical order (decode_block's) take
+    // units = tiles in [pixel tile][channel tile] order; workgroups in XCD-contiguous logical order (decode_block's) take
     // contiguous ranges
     int u0, u1;
     {
@@ -74,8 +76,8 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
     };
     auto unit_pos = [&](int u) {
         UnitPos r;
-        r.tn = u / p.tiles_m;
-        const int tm = u - r.tn * p.tiles_m;
+        const int tm = u / p.tiles_n;
+        r.tn = u - tm * p.tiles_n;
         r.im = tm / per_img;
         const int tr = tm - r.im * per_img;
         r.ty0 = (tr / tiles_x) * TH, r.tx0 = (tr % tiles_x) * TW;
@@ -176,19 +178,15 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) Mma<T>::run(acc[a][b], xb[b], xa[a]);
     };
-    // epilogue tables of the channel tile (bias, slope: BN floats each) in the free tail of the SECOND patch buffer: read back
-    // per tile instead of 33 registers held through the K loop
+    // epilogue tables of ALL channel tiles (bias, slope: tiles_n * BN floats each; the host admits at most 6 KB) in the free tail
+    // of the SECOND patch buffer: read back per tile instead of 33 registers held through the K loop
     float* const ltab = reinterpret_cast<float*>(smem + A_BYTES + X_OFF);
-    auto fill_tables = [&](int tn) {
-        if (tid < BN) {
-            const int n = tn * BN + tid;
-            const bool ok = n < p.coutT;
-            ltab[tid] = (p.bias && ok) ? p.bias[n] : 0.0f;
-            ltab[BN + tid] = (p.slope_vec && ok) ? p.slope_vec[n] : p.slope;
-        }
-    };
-    int tab_tn = cur.tn;
-    fill_tables(tab_tn);   // (the prologue's barrier below publishes it)
+    const int CT = p.tiles_n * BN;
+    for (int i = tid; i < CT; i += NW * 64) {
+        const bool ok = i < p.coutT;
+        ltab[i] = (p.bias && ok) ? p.bias[i] : 0.0f;
+        ltab[CT + i] = (p.slope_vec && ok) ? p.slope_vec[i] : p.slope;
+    }   // (the prologue's barrier below publishes it)
     const float ga_all = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
 
     // ---- prologue (once per workgroup): patch of the first chunk, weights of taps 0..D-1 -------------
@@ -237,19 +235,13 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
             aoff ^= A_BYTES;
         }
         // ---- the tile is done: its successor's first patch and taps are landing; finish it from registers ----------------
-        if (cur.tn != tab_tn) {   // (a range that crosses into the next channel tile)
-            __syncthreads();
-            tab_tn = cur.tn;
-            fill_tables(tab_tn);
-            __syncthreads();
-        }
         {
             EpiTables<TN> etab;
 #pragma unroll
             for (int b = 0; b < TN; b += 2) {   // fragment pair (b, b+1) = channels 8q .. 8q+7 of a 32-channel group
-                const int c0 = wn * (TN * 16) + frag_channel<PERM>(b, q);
+                const int c0 = cur.tn * BN + wn * (TN * 16) + frag_channel<PERM>(b, q);
                 unpack16<float>(ld128(ltab + c0), etab.bv[b]), unpack16<float>(ld128(ltab + c0 + 4), etab.bv[b + 1]);
-                unpack16<float>(ld128(ltab + BN + c0), etab.sv[b]), unpack16<float>(ld128(ltab + BN + c0 + 4), etab.sv[b + 1]);
+                unpack16<float>(ld128(ltab + CT + c0), etab.sv[b]), unpack16<float>(ld128(ltab + CT + c0 + 4), etab.sv[b + 1]);
             }
             etab.ga = ga_all;
             conv_epilogue<T, BM, BN, WM, WN, 1>(p, acc, smem + X_OFF, PatchRows<TW>{cur.im, cur.ty0, cur.tx0, p.Ho, p.Wo},

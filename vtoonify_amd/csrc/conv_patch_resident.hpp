@@ -213,18 +213,25 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
             }
             const float ga = p.gain_alpha;
             const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
-            float rp[TM][3];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) rp[a][0] = rp[a][1] = rp[a][2] = 0.0f;
+            // Fused ToRGB on the matrix cores (conv_igemm.hip::conv_epilogue has the derivation): the 8 values a lane finishes
+            // for a fragment pair, packed to bf16, ARE the pixel operand of v_mfma_f32_16x16x32_bf16 for the pair's 32 channels;
+            // the weight operand of fragment row a carries the three planes in rows 4a .. 4a + 2, so one accumulator collects
+            // all four rows and lane (q, l15) ends with the plane values of pixel l15 of tile row q -- no shuffles.
+            f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_assert(TM <= 4 && sizeof(T) == 2, "ToRGB accumulator rows");
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {   // channels 32 hp + 8q .. + 7: fragments 2 hp (first four) and 2 hp + 1
                 const int c0 = hp * 32 + q * 8;
-                float bv[8], w0[8], w1[8], w2[8];
+                float bv[8];
                 unpack16<float>(ld128(tab + c0), bv), unpack16<float>(ld128(tab + c0 + 4), bv + 4);
-                if (rgbf) {
-                    unpack16<float>(ld128(tab + BN + c0), w0), unpack16<float>(ld128(tab + BN + c0 + 4), w0 + 4);
-                    unpack16<float>(ld128(tab + 2 * BN + c0), w1), unpack16<float>(ld128(tab + 2 * BN + c0 + 4), w1 + 4);
-                    unpack16<float>(ld128(tab + 3 * BN + c0), w2), unpack16<float>(ld128(tab + 3 * BN + c0 + 4), w2 + 4);
+                u128 wfrag = u128{0u, 0u, 0u, 0u};
+                if (rgbf) {   // lane (q, l15): plane l15 & 3 (none for 3), the table holds the bf16 weights widened to fp32
+                    const int pl = (l15 & 3) < 3 ? (l15 & 3) : 0;
+                    float wv[8];
+                    unpack16<float>(ld128(tab + (1 + pl) * BN + c0), wv), unpack16<float>(ld128(tab + (1 + pl) * BN + c0 + 4), wv + 4);
+                    const u128 wp = pack16<bf16_t>(wv);
+                    const bool okw = (l15 & 3) < 3;
+                    wfrag.x = okw ? wp.x : 0u, wfrag.y = okw ? wp.y : 0u, wfrag.z = okw ? wp.z : 0u, wfrag.w = okw ? wp.w : 0u;
                 }
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
@@ -236,30 +243,18 @@ conv_patchw_kernel(const ConvArgs p, const GldsArgs g) {
                         if (p.act == VT_ACT_LRELU) v = (v > 0.0f) ? v : v * p.slope;
                         f[i] = v * ga;
                     }
+                    const u128 fpk = pack16<T>(f);
                     if (rgbf) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) rp[a][0] += f[i] * w0[i], rp[a][1] += f[i] * w1[i], rp[a][2] += f[i] * w2[i];
+                        const bool mine = (l15 >> 2) == a;
+                        u128 wa;
+                        wa.x = mine ? wfrag.x : 0u, wa.y = mine ? wfrag.y : 0u, wa.z = mine ? wfrag.z : 0u, wa.w = mine ? wfrag.w : 0u;
+                        Mma<bf16_t>::run(racc, wa, fpk);
                     }
-                    vt_bstore_hidden<4>(rout, m >= 0 ? (uint32_t)(m * p.ld_out + c0) * (uint32_t)ESZ : GLDS_OOB, pack16<T>(f));
+                    vt_bstore_hidden<4>(rout, m >= 0 ? (uint32_t)(m * p.ld_out + c0) * (uint32_t)ESZ : GLDS_OOB, fpk);
                 }
             }
             if (rgbf) {
-                // reduce-scatter over the four lane groups (each holds 16 of a pixel's 64 channels, for all 4 tile rows): after
-                // the exchange with lane + 32 a lane holds two rows summed over two groups, after the one with lane + 16 ONE row
-                // -- row q -- summed over all four (same scheme as conv3x3_c32_kernel)
-                const bool hi = q >= 2, odd = (q & 1) != 0;
-                float rr[3];
-#pragma unroll
-                for (int jc = 0; jc < 3; ++jc) {
-                    float keep_a = hi ? rp[2][jc] : rp[0][jc], keep_b = hi ? rp[3][jc] : rp[1][jc];
-                    const float send_a = hi ? rp[0][jc] : rp[2][jc], send_b = hi ? rp[1][jc] : rp[3][jc];
-                    keep_a += __shfl_xor(send_a, 32, 64);
-                    keep_b += __shfl_xor(send_b, 32, 64);
-                    float keep = odd ? keep_b : keep_a;
-                    const float send = odd ? keep_a : keep_b;
-                    keep += __shfl_xor(send, 16, 64);
-                    rr[jc] = keep;
-                }
+                const float rr[3] = {racc[0], racc[1], racc[2]};   // lane (q, l15): pixel l15 of tile row q
                 vt_vmcnt_fence<2 * TM>();   // the skip pixels (and with them the patch: older) have landed; 8 stores may fly
 #pragma unroll
                 for (int jc = 0; jc < 3; ++jc) {

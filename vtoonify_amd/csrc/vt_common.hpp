@@ -390,24 +390,6 @@ __device__ __forceinline__ u128 vt_settled(const u128& v) {
 }
 #endif
 
-// VT_EXP: experiment builds of the library (tools/flake_diag.py); 0 in the product.
-//   bit 0: the round-4 form of the lean epilogue's fused-ToRGB partial sums (SLP-packed)
-//   bit 1: the epilogue reads the up-sampled skip with system-scope loads (sc0 sc1: past the L2)
-#ifndef VT_EXP
-#define VT_EXP 0
-#endif
-
-// A float the SLP vectoriser cannot pair with its neighbours (it stays one v_mul_f32 / v_add_f32, not half of a
-// v_pk_*_f32): an empty volatile asm that "rewrites" the register.
-#ifdef VT_EMU
-static inline float vt_unpaired(float x) { return x; }
-#else
-__device__ __forceinline__ float vt_unpaired(float x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-#endif
-
 // Identity the optimiser cannot see through: values derived from the result are recomputed where they are used
 // instead of being hoisted out of a loop and kept live (LLVM hoists every loop-invariant address / predicate; in a
 // kernel whose registers are full of resident operands those copies spill -- and a scratch reload is a VMEM round

@@ -71,7 +71,8 @@ class VToonifyEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "dualstylegan",
                  in_size: int = 256, dtype: torch.dtype = torch.bfloat16,
                  device: Optional[torch.device] = None, cache_styles: bool = False,
-                 tile_hints: Optional[Dict[str, int]] = None, style_gate: bool = False, x3: bool = False):
+                 tile_hints: Optional[Dict[str, int]] = None, style_gate: bool = False, x3: bool = False,
+                 fuse_rgb128: bool = True):
         assert backbone in ("dualstylegan", "toonify")
         assert dtype in (torch.bfloat16, torch.float32)
         self.backbone = backbone
@@ -91,6 +92,7 @@ class VToonifyEngine:
         if self.device.type != "cuda" and not _lib.is_emulation():
             raise _lib.VtError("VToonifyEngine needs a GPU device (no CPU path)")
         self.cache_styles = cache_styles
+        self.fuse_rgb128 = bool(fuse_rgb128)
         # style_gate: the style path is skipped ON THE DEVICE when the W+ rows and d_s of a call equal the ones its
         # products were computed from (vt_style_gate: a bitwise compare in the frame's graph, no host sync) -- what the
         # video loop's `s_w.repeat(B,1,1)` (style_transfer.py:176: a new tensor per call, same content) needs; the
@@ -674,10 +676,10 @@ class VToonifyEngine:
                 probe.splitk_ws, probe.splitk_ws_bytes = 1 << 20, 1 << 40   # "a workspace will exist" (host query only)
                 tile = self.lib.vt_conv2d_tile(C.byref(probe))
                 fuse_rgb = tile >= 0 and tile % 1000 >= c1o and (tile // 1000000) % 100 <= 1
-                # ... except on the 128-channel patch tiles in bf16: there the fused ToRGB runs on the general epilogue (DESIGN.md
-                # 4.1m), and the plain conv on the lean / persistent kernels + one thin ToRGB launch over the stored activation is
-                # faster (the 128 -> 128 conv at 256^2: 126 us fused against 80 + 18)
-                if fuse_rgb and self.dt == K.VT_BF16 and tile // 100000000 == 1 and tile % 1000 == 128:
+                # (round 4 un-fused it on the 128-channel patch tiles in bf16, where the fused ToRGB had been sent back to the general
+                # epilogue after the wrong-image-row defect; with the cause found -- DESIGN.md 4.1n -- the lean / persistent kernels
+                # carry it again.  `fuse_rgb128=False` keeps round 4's two launches for A/B measurements.)
+                if fuse_rgb and not self.fuse_rgb128 and self.dt == K.VT_BF16 and tile // 100000000 == 1 and tile % 1000 == 128:
                     fuse_rgb = False
                 # the LAST level's activation feeds nothing but its ToRGB: with the fused epilogue on the persistent 32 -> 32
                 # kernel it is not stored at all (67 MB per 1024^2 frame; vt_conv_desc.rgb_only)
