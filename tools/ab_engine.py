@@ -27,15 +27,23 @@ def opt(name, default):
 
 
 reps, steps, B, S = opt("--reps", 3), opt("--steps", 60), opt("--batch", 4), opt("--size", 256)
+NL = opt("--lanes", 3)
 dev = torch.device("cuda:0")
 sd = {k: v.to(dev) for k, v in synth.synth_state_dict(bench.state_shapes("dualstylegan"), 0).items()}
 style = synth.synth_style(seed=17).to(dev)
 pool = [synth.synth_frames(B, S, S, seed=i).to(dev) for i in range(4)]
-lanes = 3
+lanes = NL
 streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(lanes - 1)]
 arms = []
 for a in args:
-    kw = {k: ast.literal_eval(v) for k, v in (kv.split("=") for kv in a.split(","))}
+    kw = {}
+    for kv in a.split(","):
+        k, v = kv.split("=")
+        if k == "hints":   # hints=FILE.json: a tile-hint table {conv signature: tile_hint} (engine.conv_signature)
+            import json
+            kw["tile_hints"] = {kk: int(vv) for kk, vv in json.load(open(v)).items()}
+        else:
+            kw[k] = ast.literal_eval(v)
     arms.append((a, VToonifyEngine(sd, "dualstylegan", 256, torch.bfloat16, dev, **kw)))
 
 
@@ -70,6 +78,6 @@ for name, eng in arms:
     tot = sum(ms for _, ms in per)
     print(f"--- {name}: {len(per)} launches, kernel sum {tot:.3f} ms")
     for info, ms in per:
-        if info.get("name") == "conv" and (info["cout"] == 3 or info.get("hw", (0, 0))[0] >= 64) and info["k"] in (1 * info["cin"], 9 * info["cin"]) \
-                and ":up" not in info["sig"] and info["cin"] <= 512:
+        if info.get("name") == "conv" and ("--all" in sys.argv or ((info["cout"] == 3 or info.get("hw", (0, 0))[0] >= 64) and
+                                                            ":up" not in info["sig"] and info["cin"] <= 512)):
             print(f"   {info['sig']:<34} {info['kernel']:<34} {1e3 * ms:8.1f} us")
