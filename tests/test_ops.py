@@ -158,6 +158,23 @@ def test_fused_leaky_relu_module_and_grad(dev):
 
 
 # ------------------------------------------------------------------------ MFMA lane maps
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_layout_change_at_the_model_boundary(dev, odt):
+    """vt_nchw_to_nhwc: exact (a cast and a transpose), pad channels zero, rows wider than the padded channel count untouched.
+    Narrow tensors (the 22-channel frame) take the one-thread-per-pixel kernel, wide ones the (pixel, 8-channel group) form."""
+    g = np.random.default_rng(3)
+    for n, c, h, w, ld in ((2, 22, 9, 13, 32), (1, 3, 5, 7, None), (2, 32, 4, 6, None), (1, 40, 3, 5, 48), (3, 19, 8, 8, 24)):
+        x = T(g.standard_normal((n, c, h, w)).astype(np.float32), dev)
+        cpad = (c + 7) // 8 * 8
+        ldo = ld or cpad
+        out = torch.full((n, h, w, ldo), 7.0, dtype=odt, device=dev)
+        K.nchw_to_nhwc(x, odt, ld_out=ldo, out=out)
+        want = torch.full((n, h, w, ldo), 7.0, dtype=odt)
+        want[..., :cpad] = 0
+        want[..., :c] = x.cpu().permute(0, 2, 3, 1).to(odt)
+        assert torch.equal(out.cpu(), want), (n, c, h, w, ld)
+
+
 def test_mfma_lane_maps(dev):
     """Pins the 16x16x32 bf16 / 16x16x4 f32 fragment layouts used by conv_igemm.hip with an
     ASYMMETRIC B (a transposed C-write would fail)."""

@@ -2074,6 +2074,9 @@ static bool batch_exact() {
 // persistent workgroups of the weights-resident form: one per CU.  VT_PATCHW_WGS (read per call): tests use a few workgroups
 // so that small convolutions walk several tiles each
 static int device_cus() {   // compute units of the current device (256 on MI355X), read once per device
+#ifdef VT_EMU
+    return 256;
+#else
     static int cus[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
@@ -2082,6 +2085,7 @@ static int device_cus() {   // compute units of the current device (256 on MI355
         cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
     return cus[dev];
+#endif
 }
 static int patchw_wgs() {   // persistent workgroups: one per compute unit (not the constant 256)
     const char* e = getenv("VT_PATCHW_WGS");

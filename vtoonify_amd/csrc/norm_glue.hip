@@ -492,6 +492,30 @@ nchw_to_nhwc_kernel(TO* __restrict__ out, int ld_out, const TI* __restrict__ in,
     }
 }
 
+// Few channels (the 22-channel frame at the model boundary, vtoonify.py:226): one thread per PIXEL.  A lane reads its pixel
+// from every plane (adjacent lanes, adjacent pixels: 256-byte segments per plane) and writes the pixel's whole padded row with
+// 16-byte stores, so a wavefront writes 64 complete, consecutive pixel rows -- the (pixel, 8-channel group) form above has three
+// far-apart threads write the three 16-byte thirds of every 64-byte row (34.6 us for the 4 x 22 x 256 x 256 frame batch of
+// bench.py, 1.15 TB/s: 1.4 % of the step in a kernel nobody had looked at; profiles/r05_rocprofv3_kernel_stats_lanes1.txt).
+template <typename TI, typename TO, int CPAD>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_pixel_kernel(TO* __restrict__ out, int ld_out, const TI* __restrict__ in, int n, int c, int hw) {
+    constexpr int VEC = 16 / (int)sizeof(TO);
+    const int64_t total = (int64_t)n * hw;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int img = (int)(i / hw);
+        const int p = (int)(i - (int64_t)img * hw);
+        const TI* src = in + (int64_t)img * c * hw + p;
+        float f[CPAD];
+#pragma unroll
+        for (int ch = 0; ch < CPAD; ++ch) f[ch] = ch < c ? to_f32(src[(int64_t)ch * hw]) : 0.0f;   // (c is uniform: no divergence)
+        TO* o = out + i * ld_out;
+#pragma unroll
+        for (int v = 0; v < CPAD / VEC; ++v) st128(o + v * VEC, pack16<TO>(f + v * VEC));
+    }
+}
+
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256)
 nhwc_to_nchw_kernel(TO* __restrict__ out, const TI* __restrict__ in, int ld_in, int n, int c,
@@ -702,6 +726,23 @@ static int nchw_to_nhwc_out(void* out, int ld_out, const TI* in, int n, int c, i
                             vt_stream stream) {
     const int cpad = (c + 7) / 8 * 8;
     const int64_t total = (int64_t)n * (cpad / 8) * hw;
+    // one thread per pixel for the narrow tensors of the model boundary (16-byte aligned pixel rows)
+    const int osz = out_dtype == VT_F32 ? 4 : 2;
+    if ((cpad == 8 || cpad == 16 || cpad == 24 || cpad == 32) && (out_dtype == VT_F32 || out_dtype == VT_BF16) &&
+        ((int64_t)ld_out * osz) % 16 == 0 && (uintptr_t)out % 16 == 0) {
+        const unsigned grid = grid_for((int64_t)n * hw);
+#define VT_PIX(TO_, CP_)                                                                                        \
+    {                                                                                                           \
+        auto k = nchw_to_nhwc_pixel_kernel<TI, TO_, CP_>;                                                       \
+        VT_LAUNCH(k, dim3(grid), dim3(256), stream, (TO_*)out, ld_out, in, n, c, hw);                          \
+    }
+#define VT_PIX_C(TO_) \
+    if (cpad == 8) VT_PIX(TO_, 8) else if (cpad == 16) VT_PIX(TO_, 16) else if (cpad == 24) VT_PIX(TO_, 24) else VT_PIX(TO_, 32)
+        if (out_dtype == VT_F32) { VT_PIX_C(float) } else { VT_PIX_C(bf16_t) }
+#undef VT_PIX_C
+#undef VT_PIX
+        return vt_check_launch("vt_nchw_to_nhwc");
+    }
     if (out_dtype == VT_F32) {
         auto k = nchw_to_nhwc_kernel<TI, float>;
         VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, in, n, c, hw, cpad);
