@@ -574,6 +574,29 @@ def test_conv_batch_aware_tiles(dev, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_patch_pipelined_dilated(dev, dtype):
+    """conv_patchp_kernel<.., DIL = 2> (round 5): the dilation-2 convs of the AdaResBlocks on the 256-pixel x 32-channel pipelined
+    tiles (20 x 20-pixel patches).  Against the oracle: several chunks of K, ragged tiles, a batch, residual + LeakyReLU; and the
+    plan query picks it for a batch of the 32 x 32 trunk (not for dilation 4, not under VT_BATCH_EXACT)."""
+    t = F32_TOL if dtype == torch.float32 else 8e-3
+    L = K.ACT_LRELU
+    for N, cin, H, W, cout, resid in ((2, 128, 20, 24, 32, False), (1, 64, 33, 17, 64, True), (3, 192, 16, 16, 40, True)):
+        assert _conv_case(dev, dtype, N, cin, H, W, cout, 3, 1, 2, 2, act=L, resid=resid, hint=P + 256032, expect_kind=1) < t, \
+            (N, cin, H, W, cout)
+    if dtype == torch.bfloat16:
+        import ctypes
+        from vtoonify_amd import _lib
+        x = torch.zeros((1,), dtype=torch.bfloat16, device=dev)
+        for dil, want in ((1, 101256032), (2, 101256032), (4, None)):
+            d = K.make_conv_desc(src0=x, c0=512, ld0=512, n=4, h=32, w=32, out_h=32, out_w=32, weight=x, cout=512, kh=3, kw=3,
+                                 pad=dil, dil=dil, out=x, ld_out=512, dtype=K.VT_BF16)
+            d.weight_stream = x.data_ptr()
+            d.splitk_ws, d.splitk_ws_bytes = x.data_ptr(), 1 << 40
+            code = _lib.lib().vt_conv2d_tile(ctypes.byref(d))
+            assert (code == want) if want else (code // 100000000 == 8), (dil, code)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
     """conv_patchp_kernel (csrc/conv_patch_pipe.hpp: fragments of tap s+1 read before the barrier of tap s, 4-deep weight
     ring, one patch piece per tap, LDS-DMA between the two halves of a tap) sums K in the order of conv_patch_kernel

@@ -2177,7 +2177,11 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             // the per-image plans of the parity mode); same rule as above for VT_BATCH_EXACT.
             // (planes of at most 48 x 48 pixels -- the trunk of frames up to 1536^2: the measured case; two frames of a
             // 64 x 64-pixel level would qualify by tile count, but were never measured against the weight-stationary kernel)
-            const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && a.dil == 1 && m1 <= 2304 &&
+            // (round 5: the dilation-2 convs of the AdaResBlocks too -- conv_patch_pipe.hpp, DIL = 2: 32.3 -> 2x us at 4 frames;
+            // only in the pipelined form, so not under VT_PATCH_PIPE=0)
+            const char* ppe = getenv("VT_PATCH_PIPE");
+            const bool dil_ok = a.dil == 1 || (a.dil == 2 && !(ppe && ppe[0] == '0') && !a.x3);
+            const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && dil_ok && m1 <= 2304 &&
                                        a.coutT >= 128 && !a.tile_stats && !a.in_tile_stats && !a.stats_part &&
                                        (int64_t)a.N * ptiles(16, 32) >= 256 && !batch_exact() && patch_eligible<T>(a, g);
             if (batch_patch32) {
@@ -2371,7 +2375,7 @@ int launch_patchq(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return vt_check_launch("vt_conv2d(patch, pipelined, persistent)");
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0>
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0, int DIL = 1>
 int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
     ConvArgs args = a;
@@ -2391,13 +2395,13 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         bool done = false;
         if constexpr (UP == 0 && (BN / WN / 16) % 2 == 0) {
             if (args.splitk == 1 && conv_lean<T>(args)) {   // the lean-epilogue instance: a fifth of the code
-                auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 1>;
+                auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 1, DIL>;
                 VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
                 done = true;
             }
         }
         if (!done) {
-            auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 0>;
+            auto k = conv_patchp_kernel<T, TH, BN, WM, WN, NSTB, UP, 0, DIL>;
             VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
         }
     }
@@ -2602,6 +2606,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
+            if (pipe && a.dil == 2 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 6, 0, 2>(a, g, stream);
         }
         VT_PATCH(16, 128, 4, 2, 1, 3, 2, true)
         VT_PATCH(16, 64, 4, 2, 1, 3, 2, true)

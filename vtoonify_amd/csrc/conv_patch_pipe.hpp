@@ -57,7 +57,10 @@ struct QuadRows {
     }
 };
 
-template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0, int EPI = 0>
+// DIL = 2: the dilated 3x3 convs of the AdaResBlocks (model/vtoonify.py:201-207) on the 256-pixel x 32-channel tiles of a batch
+// (round 5): the patch grows to 20 x 20 pixels (51 KB per chunk), two of them + a 6-deep ring of 8 KB slots are exactly 160 KB.
+// Dilation 4 (24 x 24 pixels, 74 KB per chunk) does not fit and stays on the weight-stationary kernel.
+template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0, int EPI = 0, int DIL = 1>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int TW = 16;
@@ -68,7 +71,8 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int BK = 8 * VEC;                 // channels per chunk (128 B)
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr bool PERM = (TN % 2 == 0);        // weight rows in fragment order: see tile_row_channel
-    constexpr int PH = TH + 2, PW = TW + 2, PROWS = PH * PW;
+    static_assert(DIL == 1 || UP == 0, "the transposed form is not dilated");
+    constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL, PROWS = PH * PW;
     constexpr int PA = ((PROWS + 7) / 8 + NW - 1) / NW;   // patch pieces (1 KB loads) per wave per chunk
     constexpr int LB = ((BN + 7) / 8 + NW - 1) / NW;      // weight loads per wave per tap
     constexpr int A_BYTES = PA * NW * 1024, B_BYTES = LB * NW * 1024;
@@ -109,7 +113,7 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     for (int i = 0; i < PA; ++i) {
         const int pr = (i * NW + wave) * 8 + lrow;
         const int py = pr / PW, px = pr - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const int iy = y0 - DIL + py, ix = x0 - DIL + px;
         const bool in = pr < PROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const uint32_t pix = (uint32_t)((img * p.H + iy) * p.W + ix);
         pa0[i] = in ? pix * (uint32_t)(p.ld0 * ESZ) + jj * 16 : GLDS_OOB;
@@ -177,7 +181,7 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     // consume them: fa[0], fb[0..TN-1], fa[1..TM-1]
     auto read_frags = [&](auto tapc, auto subc, u128 (&xa)[TM], u128 (&xb)[TN], int aoff, int boff) {
         constexpr int TAP = decltype(tapc)::value, SUB = decltype(subc)::value;
-        constexpr int ky = UP ? (TAP / 3 == 2 ? 0 : 1) : TAP / 3, kx = UP ? (TAP % 3 == 2 ? 0 : 1) : TAP % 3;
+        constexpr int ky = UP ? (TAP / 3 == 2 ? 0 : 1) : (TAP / 3) * DIL, kx = UP ? (TAP % 3 == 2 ? 0 : 1) : (TAP % 3) * DIL;
         auto ra = [&](int a) {
             const int rowc = (a + ky) * PW + kx;   // folds: a and TAP are compile-time after unrolling
             xa[a] = ld128(smem + aoff + aswz[rowc & 7][SUB] + rowc * 128);
