@@ -88,6 +88,7 @@ struct ConvArgs {
     int rgb_only;               // vt_conv_desc.rgb_only: the C-channel output is not stored (fused ToRGB only)
     int in_absdiff;             // vt_conv_desc.in_absdiff: input = cat[src0, |src0 - src1|] (thin kernel)
     int x3;             // vt_conv_desc.dtype == VT_F32X3: fp32 tensors, products as three bf16 MFMAs where the instance exists
+    int blk_pm, blk_cn;  // decode_block_2d: pixel tiles x channel tiles of the block of tiles one XCD owns (0 = channel-major order)
 };
 
 template <typename T>
@@ -288,6 +289,43 @@ __device__ __forceinline__ float conv_finish(const ConvArgs& p, float v, float b
 // read the same weight rows (tile_n) -- and neighbouring pixel tiles, which share halo rows --
 // run on the same XCD, so a conv's weight matrix is fetched from HBM/MALL once, not once per
 // XCD.  Pure speed: any placement gives the same results.  Bijective for every grid size.
+// The same logical order with the CHANNEL tile innermost: the workgroups that run together on an XCD (consecutive L) share a
+// pixel tile and fetch its patch into that XCD's L2 once; with the channel tile outermost every XCD owns one or two channel
+// tiles and all eight read the whole input (conv_upblur at the 64^2 -> 128^2 level: 192 MB of fabric traffic per launch for
+// 77 MB of operands, profiles/r05_pmc_traffic.json).  Which workgroup computes a tile does not change its bits.
+__device__ __forceinline__ void decode_block_pixel_major(const ConvArgs& p, int& tile_m, int& tile_n) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = L / p.tiles_n;
+    tile_n = L - tile_m * p.tiles_n;
+}
+// ... and with a BLOCK of blk_pm pixel tiles x blk_cn channel tiles per XCD (one-round launches without a K split whose tile
+// counts divide: the host picks the block that minimises patch + weight bytes per XCD, xcd_block()): the 32 x 32 trunk of a
+// batch on 256 x 32 tiles reads 3.7 MB per XCD instead of 5.9 (every XCD used to read the whole input).
+__device__ __forceinline__ void decode_block_2d(const ConvArgs& p, int& tile_m, int& tile_n, int& split) {
+    if (p.blk_cn == 0) {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int per_n = p.tiles_m * p.splitk;
+        tile_n = L / per_n;
+        const int rem = L - tile_n * per_n;
+        tile_m = rem / p.splitk;
+        split = rem - tile_m * p.splitk;
+        return;
+    }
+    const int per = (int)gridDim.x >> 3;                 // (gridDim.x % 8 == 0 here)
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;  // block `xcd`, tile w of it
+    const int nsbm = p.tiles_m / p.blk_pm;
+    const int sbm = xcd % nsbm, sbn = xcd / nsbm;
+    (void)per;
+    tile_m = sbm * p.blk_pm + w / p.blk_cn;
+    tile_n = sbn * p.blk_cn + w % p.blk_cn;
+    split = 0;
+}
 __device__ __forceinline__ void decode_block(const ConvArgs& p, int& tile_m, int& tile_n, int& split) {
     const int nb = gridDim.x, b = blockIdx.x;
     const int q = nb >> 3, r = nb & 7;
@@ -2375,6 +2413,22 @@ int launch_patchq(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return vt_check_launch("vt_conv2d(patch, pipelined, persistent)");
 }
 
+// block of tiles per XCD for decode_block_2d: exactly 8 blocks of pm x cn tiles, minimal patch + weight bytes per XCD
+static void xcd_block(ConvArgs& args, int64_t blocks, int64_t patch_bytes, int64_t wtile_bytes) {
+    args.blk_pm = args.blk_cn = 0;
+    if (args.splitk != 1 || blocks < 8 || blocks % 8 != 0) return;
+    const int per = (int)(blocks / 8);
+    int64_t best = -1;
+    for (int cn = 1; cn <= args.tiles_n; ++cn) {
+        if (args.tiles_n % cn != 0 || per % cn != 0) continue;
+        const int pm = per / cn;
+        if (pm < 1 || args.tiles_m % pm != 0) continue;
+        if ((int64_t)(args.tiles_m / pm) * (args.tiles_n / cn) != 8) continue;
+        const int64_t cost = pm * patch_bytes + cn * wtile_bytes;
+        if (best < 0 || cost < best) best = cost, args.blk_pm = pm, args.blk_cn = cn;
+    }
+}
+
 template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4, int UP = 0, int DIL = 1>
 int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -2391,6 +2445,8 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
         vt_set_error("vt_conv2d: too many tiles");
         return VT_ERR_ARG;
     }
+    if (UP == 0)
+        xcd_block(args, blocks, (int64_t)(TH + 2 * DIL) * (16 + 2 * DIL) * a.cin * (int)sizeof(T), (int64_t)BN * a.K * (int)sizeof(T));
     if (args.phase != 2) {
         bool done = false;
         if constexpr (UP == 0 && (BN / WN / 16) % 2 == 0) {

@@ -96,7 +96,7 @@ conv_patchp_kernel(const ConvArgs p, const GldsArgs g) {
     const int wave = vt_uniform(tid >> 6) & (NW - 1);
     const int wm = wave / WN, wn = wave % WN;
     int tile_m, tile_n, split;
-    decode_block(p, tile_m, tile_n, split);
+    decode_block_2d(p, tile_m, tile_n, split);
     // (UP: tiles of quads over (H+1) x (W+1); p.Ho x p.Wo = (2H+1) x (2W+1) is the z image)
     const int tiles_x = UP ? (p.W + 1 + TW - 1) / TW : (p.Wo + TW - 1) / TW;
     const int tiles_y = UP ? (p.H + 1 + TH - 1) / TH : (p.Ho + TH - 1) / TH;

@@ -81,7 +81,8 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         tile_m = (int)(blockIdx.x / (unsigned)p.tiles_n);
         tile_step = (int)(gridDim.x / (unsigned)p.tiles_n);
     } else {
-        decode_block(p, tile_m, tile_n, split);
+        decode_block_pixel_major(p, tile_m, tile_n);   // (no K split in this kernel)
+        split = 0;
         tile_step = 0x40000000;
     }
     const int per_img = g.tiles_y * g.tiles_x;
