@@ -42,9 +42,14 @@ for a in args:
         if k == "hints":   # hints=FILE.json: a tile-hint table {conv signature: tile_hint} (engine.conv_signature)
             import json
             kw["tile_hints"] = {kk: int(vv) for kk, vv in json.load(open(v)).items()}
+        elif k == "lib":   # lib=PATH: an experiment build of the library (vtoonify_amd.build --variant); an engine keeps the
+            libpath = v    # handle it was constructed with, so arms with different libraries coexist in one process
         else:
             kw[k] = ast.literal_eval(v)
+    from vtoonify_amd import _lib
+    _lib.use_library(locals().pop("libpath", None) or _lib.DEFAULT_LIB)
     arms.append((a, VToonifyEngine(sd, "dualstylegan", 256, torch.bfloat16, dev, **kw)))
+    _lib.use_library(_lib.DEFAULT_LIB)
 
 
 def rate(eng):

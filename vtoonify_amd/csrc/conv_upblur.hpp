@@ -136,6 +136,9 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
 
     // ---- blur constants (phase 3), fixed for the workgroup ----------------------------------------------------
     constexpr int NV = CN / VEC;                 // 16-byte channel vectors per pixel
+    // (two row groups of 14 rows instead of four of 7 on the 8-wave forms -- 17 instead of 20 row iterations per SIMD -- measured
+    // SLOWER: 227 against 190 us at the top level, profiles/r05_upblur_rows.txt: the phase is bound by the latency of its
+    // LDS round trips, which fewer resident waves hide worse, not by its instruction count)
     constexpr int GROUPS = NT / (TX * NV) >= 1 ? NT / (TX * NV) : 1;
     constexpr int ROWS = TY / GROUPS;
     static_assert(TX * NV <= NT && TY % GROUPS == 0, "one thread per (column, channel vector, row group)");
@@ -339,16 +342,21 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
         if (grp < GROUPS) {
             const int ov = v0 + col;
             // running sums by age: o1 / o2 / o3 have received 1 / 2 / 3 vertical taps; the row that completes o3
-            // finishes output row rr - 3.  One row per iteration of a REAL loop (rotating the sums costs 24 moves
-            // per row; unrolled bodies kept 4 rows of unpacked pixels live and spilled).
-            float o1[VEC], o2[VEC], o3[VEC];
+            // finishes output row rr - 3.  The three sums keep their REGISTERS and rotate their ROLES (round 5): a row adds its
+            // taps in place (o2 += h ky2 becomes the new o3, o1 += h ky1 the new o2, the finished o3 restarts as h ky0 + bias),
+            // and three rows later every variable is back in its role -- the one-row loop body moved all 24 sums every row (26
+            // v_mov per 170 instructions; unrolled 4 rows with static slots it kept four rows of unpacked pixels live and
+            // spilled).  Same operands in the same order: the same bits.  Worth 1 % of the kernel (same box: 571 -> 565 us over
+            // the five levels): the phase waits for LDS, it does not run out of issue slots.
+            float oa[VEC], ob[VEC], oc[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o1[k] = o2[k] = o3[k] = 0.0f;
+            for (int k = 0; k < VEC; ++k) oa[k] = ob[k] = oc[k] = 0.0f;
             T* o = (T*)p.out + (((int64_t)img * OH + u0 + r0w - 3) * OW + ov) * p.ld_out + nch;   // row (rr - 3) of this thread
             const bool colok = ov < OW;
             const unsigned char *z0 = zt[0], *z1 = zt[1], *z2 = zt[2], *z3 = zt[3];
-#pragma unroll 1
-            for (int rr = 0; rr < ROWS + 3; ++rr) {
+            int rr = 0;
+            auto row = [&](float (&o1)[VEC], float (&o2)[VEC], float (&o3)[VEC]) {
+                vt_sched_fence();   // one row's unpacked pixels live at a time
                 float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
                 unpack16<T>(ld128(z0), f0);
                 unpack16<T>(ld128(z1), f1);
@@ -361,9 +369,9 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                     h[k] = fmaf(f1[k], kx[1], f0[k] * kx[0]) + fmaf(f3[k], kx[3], f2[k] * kx[2]);
                     const float v = fmaf(h[k], ky[3], o3[k]);     // completes output row rr - 3
                     f[k] = v * (v > 0.0f ? gpos[k] : gneg[k]);
-                    o3[k] = fmaf(h[k], ky[2], o2[k]);
-                    o2[k] = fmaf(h[k], ky[1], o1[k]);
-                    o1[k] = fmaf(h[k], ky[0], bv[k]);
+                    o2[k] = fmaf(h[k], ky[2], o2[k]);             // -> the next row's o3
+                    o1[k] = fmaf(h[k], ky[1], o1[k]);             // -> the next row's o2
+                    o3[k] = fmaf(h[k], ky[0], bv[k]);             // -> the next row's o1
                 }
                 const int u = rr - 3;
                 if (u >= 0 && u0 + r0w + u < OH && colok) {
@@ -374,7 +382,17 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                     }
                 }
                 o += ostep;
+                ++rr;
+            };
+            constexpr int NROW = ROWS + 3;
+#pragma unroll 1
+            for (int t = 0; t < NROW / 3; ++t) {
+                row(oa, ob, oc);
+                row(oc, oa, ob);
+                row(ob, oc, oa);
             }
+            if constexpr (NROW % 3 >= 1) row(oa, ob, oc);
+            if constexpr (NROW % 3 == 2) row(oc, oa, ob);
         }
         // (PERSIST: the wait + barrier at the top of the next tile's chunk loop also fences the z tile)
         if (!PERSIST) break;
