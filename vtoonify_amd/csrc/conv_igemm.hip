@@ -1697,6 +1697,16 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int... I, typename F>
+__device__ __forceinline__ void vt_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void vt_static_for(F&& f) {
+    vt_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 #include "conv_fullk.hpp"
 #include "conv_fullkw.hpp"
 #include "conv_upblur.hpp"

@@ -37,14 +37,7 @@
 // The engine keeps conv_upblur_kernel (profiles/r04_up_by_parity.txt).
 #pragma once
 
-template <int... I, typename F>
-__device__ __forceinline__ void vt_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void vt_static_for(F&& f) {
-    vt_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
+// (vt_static_for: conv_igemm.hip, in front of the kernel headers)
 
 // UP: tile row -> z pixel (2I'+pa, 2J'+pb) of the (2H+1) x (2W+1) transposed-conv output, or -1.  Parity 0 exists for
 // I' in [0, H], parity 1 for I' in [0, H-1] (same for columns).

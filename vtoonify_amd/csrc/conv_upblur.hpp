@@ -355,14 +355,25 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
             const bool colok = ov < OW;
             const unsigned char *z0 = zt[0], *z1 = zt[1], *z2 = zt[2], *z3 = zt[3];
             int rr = 0;
-            auto row = [&](float (&o1)[VEC], float (&o2)[VEC], float (&o3)[VEC]) {
+            // ... and in the persistent 8-wave form (the 1024^2 level) the four LDS reads of a row are issued ONE ROW AHEAD, into
+            // the other of two register sets (roles again: a call consumes `cur`, fills `nxt`): 183 -> 171 us at 4 frames, same
+            // box; the 4-wave and multi-chunk forms lose 1-3 us to it (two resident workgroups / a register-hungrier K loop
+            // hide the round trip already) and read their row where they use it (profiles/r05_upblur_rows.txt).
+            constexpr bool PF = PERSIST != 0;
+            u128 ra[4], rb[4];
+            if constexpr (PF) ra[0] = ld128(z0), ra[1] = ld128(z1), ra[2] = ld128(z2), ra[3] = ld128(z3);
+            auto row = [&](float (&o1)[VEC], float (&o2)[VEC], float (&o3)[VEC], u128 (&cur)[4], u128 (&nxt)[4], bool more) {
                 vt_sched_fence();   // one row's unpacked pixels live at a time
-                float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
-                unpack16<T>(ld128(z0), f0);
-                unpack16<T>(ld128(z1), f1);
-                unpack16<T>(ld128(z2), f2);
-                unpack16<T>(ld128(z3), f3);
+                if constexpr (!PF) cur[0] = ld128(z0), cur[1] = ld128(z1), cur[2] = ld128(z2), cur[3] = ld128(z3);
                 z0 += ZLINES * 128; z1 += ZLINES * 128; z2 += ZLINES * 128; z3 += ZLINES * 128;
+                if constexpr (PF) {
+                    if (more) nxt[0] = ld128(z0), nxt[1] = ld128(z1), nxt[2] = ld128(z2), nxt[3] = ld128(z3);
+                }
+                float f0[VEC], f1[VEC], f2[VEC], f3[VEC], h[VEC];
+                unpack16<T>(cur[0], f0);
+                unpack16<T>(cur[1], f1);
+                unpack16<T>(cur[2], f2);
+                unpack16<T>(cur[3], f3);
                 float f[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -384,15 +395,21 @@ conv_upblur_kernel(const ConvArgs p, const UpblurArgs g) {
                 o += ostep;
                 ++rr;
             };
+            // call number c of a period of six: sums in role rotation c % 3, register sets alternating
+            auto step = [&](auto cc, bool more) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c % 6 == 0) row(oa, ob, oc, ra, rb, more);
+                else if constexpr (c % 6 == 1) row(oc, oa, ob, rb, ra, more);
+                else if constexpr (c % 6 == 2) row(ob, oc, oa, ra, rb, more);
+                else if constexpr (c % 6 == 3) row(oa, ob, oc, rb, ra, more);
+                else if constexpr (c % 6 == 4) row(oc, oa, ob, ra, rb, more);
+                else row(ob, oc, oa, rb, ra, more);
+            };
             constexpr int NROW = ROWS + 3;
 #pragma unroll 1
-            for (int t = 0; t < NROW / 3; ++t) {
-                row(oa, ob, oc);
-                row(oc, oa, ob);
-                row(ob, oc, oa);
-            }
-            if constexpr (NROW % 3 >= 1) row(oa, ob, oc);
-            if constexpr (NROW % 3 == 2) row(oc, oa, ob);
+            for (int t = 0; t < NROW / 6; ++t)
+                vt_static_for<6>([&](auto cc) { step(cc, t * 6 + decltype(cc)::value + 1 < NROW); });
+            vt_static_for<NROW % 6>([&](auto cc) { step(cc, (NROW / 6) * 6 + decltype(cc)::value + 1 < NROW); });
         }
         // (PERSIST: the wait + barrier at the top of the next tile's chunk loop also fences the z tile)
         if (!PERSIST) break;
