@@ -1366,6 +1366,53 @@ def test_conv_transpose_blur_persistent_form(dev, dtype, monkeypatch):
     assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+def test_conv_transpose_blur_rows_form(dev, monkeypatch):
+    """conv_upblur_rows.hpp (bf16, Cin = 64 / 128, the two top levels of a frame): one wave per 28-column strip, horizontal blur
+    as an MFMA on the finished accumulators, vertical blur in registers.  Forced here (VT_UPBLUR_ROWS=1) on small images: against
+    the oracle's conv_transpose2d -> upfirdn2d -> fused_leaky_relu, against the tile kernel of conv_upblur.hpp (same rounding
+    points: a few ulps of bf16 apart), several units per wave / one unit per wave (the same bits: the partition does not reach the
+    arithmetic), a frame inside a batch = the frame alone, a cout that is not a multiple of the tile, a FIR whose taps are not
+    bf16 numbers (remainder product)."""
+    dtype = torch.bfloat16
+    g = np.random.default_rng(77)
+    k1 = np.array([1, 3, 3, 1], np.float32)
+    fir_std = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)
+    k2 = np.array([0.9, 3.1, 2.7, 1.3], np.float32)
+    fir_odd = (np.outer(k1, k2) / 64.0 * 4.0).astype(np.float32)
+    for N, cin, H, W, cout, fir, wgs in [(2, 64, 21, 19, 32, fir_std, "3"), (1, 128, 13, 31, 40, fir_std, "2"),
+                                         (1, 64, 9, 45, 64, fir_odd, "1")]:
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xt = K.nchw_to_nhwc(T(x, dev), dtype)
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        xq = xt.float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        z = O.conv_transpose2d(xq, wq.transpose(1, 0, 2, 3), stride=2)
+        ref = O.fused_leaky_relu(O.upfirdn2d(z, fir, pad=(1, 1)), b)
+
+        def run(xin, n, rows, wg=None):
+            monkeypatch.setenv("VT_UPBLUR_ROWS", rows)
+            if wg:
+                monkeypatch.setenv("VT_UPBLUR_WGS", wg)
+            else:
+                monkeypatch.delenv("VT_UPBLUR_WGS", raising=False)
+            out = torch.zeros((n, 2 * H, 2 * W, cout), dtype=dtype, device=dev)
+            K.conv2d(src0=xin, c0=cin, ld0=cin, n=n, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dtype),
+                     up_fir=T(fir, dev), tile_hint=32)
+            return out
+        y_rows = run(xt, N, "1", wgs)
+        y = y_rows.float().cpu().permute(0, 3, 1, 2).numpy()
+        assert rel_err(y, ref) < 1.2e-2, (N, cin, H, W, cout)
+        y_tile = run(xt, N, "0")
+        assert rel_err(y, y_tile.float().cpu().permute(0, 3, 1, 2).numpy()) < 8e-3, (N, cin, H, W, cout)
+        assert torch.equal(run(xt, N, "1"), y_rows), "one unit per wave"
+        if N > 1:
+            assert torch.equal(run(xt[1:].contiguous(), 1, "1", wgs)[0], y_rows[1]), "frame alone"
+    monkeypatch.delenv("VT_UPBLUR_ROWS")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose_blur_kernel(dev, dtype, monkeypatch):
     """vt_conv_desc.up_fir: conv_transpose2d(3x3, stride 2) on the matrix cores + the 4x4 FIR blur from LDS + bias

@@ -35,6 +35,25 @@ pool = [synth.synth_frames(B, S, S, seed=i).to(dev) for i in range(4)]
 lanes = NL
 streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(lanes - 1)]
 arms = []
+envs = {}
+
+
+class arm_env:   # the arm's environment switches, for the duration of a with-block
+    def __init__(self, name):
+        self.kv = envs.get(name, {})
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 for a in args:
     kw = {}
     for kv in a.split(","):
@@ -42,6 +61,8 @@ for a in args:
         if k == "hints":   # hints=FILE.json: a tile-hint table {conv signature: tile_hint} (engine.conv_signature)
             import json
             kw["tile_hints"] = {kk: int(vv) for kk, vv in json.load(open(v)).items()}
+        elif k == "env":   # env=NAME:VALUE: an environment switch of the library, set while this arm builds plans, captures and runs
+            envs.setdefault(a, {})[v.split(":")[0]] = v.split(":")[1]
         elif k == "lib":   # lib=PATH: an experiment build of the library (vtoonify_amd.build --variant); an engine keeps the
             libpath = v    # handle it was constructed with, so arms with different libraries coexist in one process
         else:
@@ -71,15 +92,18 @@ def rate(eng):
 
 outs = []
 for name, eng in arms:
-    outs.append(eng.forward(pool[0], style, 0.5, shared_style=True, use_graph=False, lane=0).clone())
+    with arm_env(name):
+        outs.append(eng.forward(pool[0], style, 0.5, shared_style=True, use_graph=False, lane=0).clone())
 print("outputs equal across arms:", all(torch.equal(outs[0], o) for o in outs[1:]),
       "max abs diff", max(float((outs[0] - o).abs().max()) for o in outs[1:]) if len(outs) > 1 else 0.0)
 for r in range(reps):
     for name, eng in arms:
-        print(f"rep {r}  {name:<40} {rate(eng):8.1f} frames/s", flush=True)
+        with arm_env(name):
+            print(f"rep {r}  {name:<40} {rate(eng):8.1f} frames/s", flush=True)
 for name, eng in arms:
-    plan = eng.plan_for(B, S, S, True, True)
-    per = eng.time_ops(plan, iters=5)
+    with arm_env(name):
+        plan = eng.plan_for(B, S, S, True, True)
+        per = eng.time_ops(plan, iters=5)
     tot = sum(ms for _, ms in per)
     print(f"--- {name}: {len(per)} launches, kernel sum {tot:.3f} ms")
     for info, ms in per:

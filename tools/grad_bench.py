@@ -74,19 +74,19 @@ def main():
         y = fwd()
         go = torch.randn(y.shape, generator=g).to(dev).to(y.dtype)
         macs = n * cin * cout * 9 * (h * h)       # per contraction (transposed: input pixels x taps)
-        t_f = timeit(lambda: fwd(), a.reps)
 
-        def bwd_all():
-            yy = fwd()
-            torch.autograd.grad(yy, (x, w), go)
+        def only(which):   # a Function's needs_input_grad follows requires_grad of its inputs: switch the other one off
+            x.requires_grad_(which != "w")
+            w.requires_grad_(which != "x")
 
-        def bwd_in():
-            yy = fwd()
-            torch.autograd.grad(yy, (x,), go)
-
-        t_all = timeit(bwd_all, a.reps) - t_f
-        t_in = timeit(bwd_in, a.reps) - t_f
-        t_w = t_all - t_in
+        only("both")
+        with torch.no_grad():
+            t_f = timeit(lambda: fwd(), a.reps)
+        only("x")
+        t_in = timeit(lambda: torch.autograd.grad(fwd(), (x,), go), a.reps) - t_f
+        only("w")
+        t_w = timeit(lambda: torch.autograd.grad(fwd(), (w,), go), a.reps) - t_f
+        only("both")
         tf = lambda ms: round(2 * macs / (ms * 1e-3) / 1e12, 1)  # noqa: E731
         rows.append({"op": name, "dtype": str(dt).split(".")[-1], "forward_ms": round(t_f, 3), "grad_input_ms": round(t_in, 3),
                      "grad_weight_ms": round(t_w, 3), "forward_tflops": tf(t_f), "grad_input_tflops": tf(t_in),

@@ -1710,6 +1710,8 @@ __device__ __forceinline__ void vt_static_for(F&& f) {
 #include "conv_fullk.hpp"
 #include "conv_fullkw.hpp"
 #include "conv_upblur.hpp"
+static int device_cus();
+#include "conv_upblur_rows.hpp"
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
 #include "conv_patch_resident.hpp"
@@ -2551,6 +2553,11 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         const bool db = de ? chunks >= atoi(de) : (chunks >= 4 && (t.bn == 16 || wgs_all <= 768));
         // (single-stage 32-channel forms are capped at 256 registers -- 2 workgroups per CU, a few cold values spilled: 40 vs
         // 51 us and 54 vs 77 us on the 256^2 / 512^2-pixel levels)
+        if constexpr (sizeof(T) == 2) {
+            // the two top levels (Cin <= 128, >= 128^2 input pixels): one wave per strip, horizontal blur on the matrix cores,
+            // no z tile (conv_upblur_rows.hpp).  Other bits than the tile kernels below, so the choice is by shape only.
+            if (uprows_wanted<T>(a, t.bn)) return launch_uprows<T>(a, stream);
+        }
         if constexpr (sizeof(T) == 2) {
             // single-chunk layers (the 1024^2 level) with >= 4 tiles per CU: persistent 8-wave workgroups on 16 x 16-quad tiles
             // -- the 36 KB of weights stay in LDS instead of being re-fetched by every tile (more than the tile's 28 KB

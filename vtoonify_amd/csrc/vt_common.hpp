@@ -420,6 +420,18 @@ __device__ __forceinline__ u128 vt_bload16(const BufRsrc& r, uint32_t voff) {
     return __builtin_bit_cast(u128, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, 0, 0));
 }
 #endif
+// ... and the range-checked 16-byte store: an offset at or beyond the descriptor's size (GLDS_OOB) writes nothing -- a
+// predicated store without a branch, so a kernel's row step stays ONE basic block for the scheduler (conv_upblur_rows.hpp)
+#ifdef VT_EMU
+static inline void vt_bstore16(const BufRsrc& r, uint32_t voff, const u128& v) {
+    if ((uint64_t)voff + 16 <= r.nrec) memcpy(const_cast<char*>(r.base) + voff, &v, 16);
+}
+#else
+__device__ __forceinline__ void vt_bstore16(const BufRsrc& r, uint32_t voff, const u128& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v),
+                                           r.r, voff, 0, 0);
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // Buffer loads / stores the COMPILER DOES NOT SEE (inline asm), for the per-step residual read and output write
