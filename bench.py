@@ -81,6 +81,8 @@ def pmc_traffic(kernel_class: str):
             lead = f"{name}<{tt}"
         elif name == "conv_upblur_kernel":
             lead = f"{name}<{tt}, {bn},"
+        elif name == "conv_upblur_rows_kernel":   # (template argument: the input channel count)
+            lead = f"{name}<"
         else:
             lead = f"{name}<{tt}, {bm // 16 if name == 'conv_patch_kernel' else bm}, {bn},"
         hit = [v for k, v in table.items() if k.startswith(lead)]

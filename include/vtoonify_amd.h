@@ -188,7 +188,8 @@ typedef struct vt_conv_desc {
      * a*3+b as conv_transpose2d indexes them), h x w the INPUT size and out_h = 2h, out_w = 2w.  up_fir: (4,4) fp32
      * device taps, an outer product (make_kernel of a 1-D list, model.py:21-29).  The transposed conv runs on the
      * matrix cores (9 MACs per input pixel instead of the 36 of the phases == 4 form), the blur on the vector
-     * ALUs out of LDS; the (2h+1)^2 intermediate never reaches HBM.  KIND 5 of vt_conv2d_tile.  kh = kw = 3,
+     * ALUs out of LDS; the (2h+1)^2 intermediate never reaches HBM.  KIND 5 of vt_conv2d_tile (KIND 9: bf16 layers of
+     * 64 / 128 input channels and >= 128^2 input pixels, where the blur runs on the matrix cores too).  kh = kw = 3,
      * phases = 1, single source, NHWC output in the compute dtype, no residual. */
     const float* up_fir;
     /* ABI 3: horizontal padding + 1 when it differs from `pad` (0 = same as `pad`): the (1,5) / (5,1) convs of

@@ -1403,6 +1403,12 @@ def test_conv_transpose_blur_rows_form(dev, monkeypatch):
                      up_fir=T(fir, dev), tile_hint=32)
             return out
         y_rows = run(xt, N, "1", wgs)
+        import ctypes
+        from vtoonify_amd import _lib
+        code = _lib.lib().vt_conv2d_tile(ctypes.byref(K.make_conv_desc(
+            src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3, bias=T(b, dev),
+            act=K.ACT_LRELU, gain=2 ** 0.5, out=y_rows, ld_out=cout, dtype=K.dt_code(dtype), up_fir=T(fir, dev), tile_hint=32)))
+        assert code // 100000000 == 9 and code % 1000000 == 28032, code     # reported as its own plan kind (28-column strips)
         y = y_rows.float().cpu().permute(0, 3, 1, 2).numpy()
         assert rel_err(y, ref) < 1.2e-2, (N, cin, H, W, cout)
         y_tile = run(xt, N, "0")

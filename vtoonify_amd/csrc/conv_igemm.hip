@@ -2843,7 +2843,12 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
         const bool glds = d->dtype == VT_BF16 ? glds_eligible<bf16_t>(a, g) : glds_eligible<float>(a, g);
         kind = glds ? 2 : 0;
     }
-    return kind * 100000000 + t.splitk * 1000000 + t.bm * 1000 + t.bn;
+    int bm = t.bm;
+    if (kind == 5 && d->dtype == VT_BF16) {   // 9 = the strip-marching form of the top up-sampling convs (conv_upblur_rows.hpp)
+        UpblurArgs ub;
+        if (uprows_wanted<bf16_t>(a, t.bn) && upblur_eligible<bf16_t>(a, ub, 2, UR_OW)) kind = 9, bm = UR_OW;
+    }
+    return kind * 100000000 + t.splitk * 1000000 + bm * 1000 + t.bn;
 }
 
 extern "C" int vt_conv2d_splitk_mode(const vt_conv_desc* d) {
