@@ -1391,7 +1391,7 @@ def test_conv_transpose_blur_rows_form(dev, monkeypatch):
         z = O.conv_transpose2d(xq, wq.transpose(1, 0, 2, 3), stride=2)
         ref = O.fused_leaky_relu(O.upfirdn2d(z, fir, pad=(1, 1)), b)
 
-        def run(xin, n, rows, wg=None):
+        def run(xin, n, rows, wg=None, hint=32):
             monkeypatch.setenv("VT_UPBLUR_ROWS", rows)
             if wg:
                 monkeypatch.setenv("VT_UPBLUR_WGS", wg)
@@ -1400,7 +1400,7 @@ def test_conv_transpose_blur_rows_form(dev, monkeypatch):
             out = torch.zeros((n, 2 * H, 2 * W, cout), dtype=dtype, device=dev)
             K.conv2d(src0=xin, c0=cin, ld0=cin, n=n, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
                      bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dtype),
-                     up_fir=T(fir, dev), tile_hint=32)
+                     up_fir=T(fir, dev), tile_hint=hint)
             return out
         y_rows = run(xt, N, "1", wgs)
         import ctypes
@@ -1414,6 +1414,9 @@ def test_conv_transpose_blur_rows_form(dev, monkeypatch):
         y_tile = run(xt, N, "0")
         assert rel_err(y, y_tile.float().cpu().permute(0, 3, 1, 2).numpy()) < 8e-3, (N, cin, H, W, cout)
         assert torch.equal(run(xt, N, "1"), y_rows), "one unit per wave"
+        # the plan's tile width follows the batch (16 channels for few-tile launches): it must not decide between this kernel
+        # and the tile kernels (round 5: it did, and a frame of a video batch differed from the frame alone)
+        assert torch.equal(run(xt, N, "1", wgs, hint=16), y_rows), "tile hint 16"
         if N > 1:
             assert torch.equal(run(xt[1:].contiguous(), 1, "1", wgs)[0], y_rows[1]), "frame alone"
     monkeypatch.delenv("VT_UPBLUR_ROWS")

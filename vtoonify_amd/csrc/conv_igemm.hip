@@ -2556,7 +2556,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         if constexpr (sizeof(T) == 2) {
             // the two top levels (Cin <= 128, >= 128^2 input pixels): one wave per strip, horizontal blur on the matrix cores,
             // no z tile (conv_upblur_rows.hpp).  Other bits than the tile kernels below, so the choice is by shape only.
-            if (uprows_wanted<T>(a, t.bn)) return launch_uprows<T>(a, stream);
+            if (uprows_wanted<T>(a)) return launch_uprows<T>(a, stream);
         }
         if constexpr (sizeof(T) == 2) {
             // single-chunk layers (the 1024^2 level) with >= 4 tiles per CU: persistent 8-wave workgroups on 16 x 16-quad tiles
@@ -2843,12 +2843,12 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
         const bool glds = d->dtype == VT_BF16 ? glds_eligible<bf16_t>(a, g) : glds_eligible<float>(a, g);
         kind = glds ? 2 : 0;
     }
-    int bm = t.bm;
+    int bm = t.bm, bn = t.bn;
     if (kind == 5 && d->dtype == VT_BF16) {   // 9 = the strip-marching form of the top up-sampling convs (conv_upblur_rows.hpp)
         UpblurArgs ub;
-        if (uprows_wanted<bf16_t>(a, t.bn) && upblur_eligible<bf16_t>(a, ub, 2, UR_OW)) kind = 9, bm = UR_OW;
+        if (uprows_wanted<bf16_t>(a) && upblur_eligible<bf16_t>(a, ub, 2, UR_OW)) kind = 9, bm = UR_OW, bn = 32;
     }
-    return kind * 100000000 + t.splitk * 1000000 + bm * 1000 + t.bn;
+    return kind * 100000000 + t.splitk * 1000000 + bm * 1000 + bn;
 }
 
 extern "C" int vt_conv2d_splitk_mode(const vt_conv_desc* d) {

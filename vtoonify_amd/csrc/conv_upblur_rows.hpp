@@ -367,14 +367,16 @@ __global__ void __launch_bounds__(512, 1) conv_upblur_rows_kernel(const ConvArgs
 }
 
 // Host side.  `force` (VT_UPBLUR_ROWS=1, tests) ignores the size threshold; the choice never looks at the batch.
+// (Not by the tile width of the plan either: that one follows the batch -- 16-channel tiles for few-tile launches -- and the
+// tile kernels give the same bits at both widths; this kernel always works on 32 channels per workgroup.)
 template <typename T>
-static bool uprows_wanted(const ConvArgs& a, int bn) {
+static bool uprows_wanted(const ConvArgs& a) {
     if constexpr (sizeof(T) != 2) {
         return false;
     } else {
         const char* e = getenv("VT_UPBLUR_ROWS");
         if (e && e[0] == '0') return false;
-        if (bn != 32 || (a.cin != 64 && a.cin != 128)) return false;
+        if (a.cin != 64 && a.cin != 128) return false;
         if (a.ld0 % 8 != 0 || (uintptr_t)a.src0 % 16 != 0 || a.ld_out % 8 != 0 || (uintptr_t)a.out % 16 != 0) return false;
         if ((int64_t)a.N * 4 * a.H * a.W * a.ld_out * 2 >= ((int64_t)1 << 31) - 4096) return false;   // range-checked stores
         return (e && e[0] == '1') || (int64_t)a.H * a.W >= 128 * 128;
