@@ -8,6 +8,7 @@
 #   bench        bench.py with default flags + per-kernel table
 #   benchq       bench.py --no-extras --no-video --no-cpu-baseline (value, single_stream, kernel table)
 #   prof         rocprofv3 --kernel-trace --stats of the bench command, one and three frames in flight
+#   prof1        the lanes-1 half of prof
 #   pmc          rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) over the eager single-stream command
 #   smoke        __graft_entry__.smoke()
 #   stress       two engine lanes / the video driver in steady state against serial results (tools/flake_lanes.py, flake_video.py)
@@ -44,6 +45,11 @@ while [ $# -gt 0 ]; do
         python tools/rocpd_stats.py $(find $O/prof${L}_$TAG -name "*.db" | head -1) > $O/rocprofv3_kernel_stats_lanes${L}_$TAG.txt 2>&1
         rm -rf $O/prof${L}_$TAG
       done
+      head -14 $O/rocprofv3_kernel_stats_lanes1_$TAG.txt | cut -c1-150 ;;
+    prof1)   # lanes 1 only (short calls)
+      (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof1_$TAG -o bench -- $B --lanes 1 > $GRAFT_REPO_ROOT/$O/prof1_$TAG.log 2>&1)
+      python tools/rocpd_stats.py $(find $O/prof1_$TAG -name "*.db" | head -1) > $O/rocprofv3_kernel_stats_lanes1_$TAG.txt 2>&1
+      rm -rf $O/prof1_$TAG
       head -14 $O/rocprofv3_kernel_stats_lanes1_$TAG.txt | cut -c1-150 ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
