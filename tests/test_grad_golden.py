@@ -117,3 +117,44 @@ def test_upfirdn2d_and_fused_leaky_relu_double_backward(dev):
     for a, b in zip(got, want):
         err = float((a.cpu() - b).abs().max() / b.abs().max())
         assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("case", [
+    # n, ci, co, h, w, k, stride, pad, dil, transposed, chunk bytes (None = one GEMM)
+    (2, 8, 16, 9, 7, 3, 1, 1, 1, False, None),
+    (2, 5, 6, 9, 7, 3, 1, 1, 1, False, None),            # channel counts that are no multiple of 8
+    (3, 8, 8, 12, 10, 3, 2, 1, 1, False, None),           # stride 2 (encoder convs, vtoonify.py:167-176)
+    (2, 8, 8, 12, 11, 3, 1, 2, 2, False, None),           # dilation 2 (AdaResBlock, dualstylegan.py:24-45)
+    (2, 8, 8, 10, 10, 1, 1, 0, 1, False, None),           # 1x1 (ToRGB)
+    (2, 8, 16, 6, 5, 3, 2, 0, 1, True, None),             # conv_transpose2d stride 2 (up-sampling StyledConv, model.py:273-286)
+    (3, 8, 16, 9, 7, 3, 1, 1, 1, False, 20000),           # cut into groups of images
+    (2, 8, 16, 9, 7, 3, 1, 1, 1, False, 3000),            # cut into groups of rows
+])
+def test_weight_gradient_contraction_vs_torch(dev, case, monkeypatch):
+    """conv2d_gradfix's weight gradient (pixels as the contraction axis of one split-K GEMM, op/conv2d_gradfix.py:188-223 in
+    the reference = cudnn_convolution_backward_weight) against torch autograd of F.conv2d / F.conv_transpose2d on the CPU,
+    fp32 (bar 2e-5 relative to max|ref|) and bf16 tensors (2e-2, against the same gradient of the bf16-rounded operands)."""
+    n, ci, co, h, w, k, s, p, d, transposed, chunk = case
+    if chunk:
+        monkeypatch.setattr(conv2d_gradfix, "_GW_CHUNK_BYTES", chunk)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g)
+    F = torch.nn.functional
+    if transposed:
+        wt = torch.randn(ci, co, k, k, generator=g) * 0.1
+        ref_fn = lambda a, b: F.conv_transpose2d(a, b, stride=s, padding=p, dilation=d)
+        our_fn = lambda a, b: conv2d_gradfix.conv_transpose2d(a, b, stride=s, padding=p, dilation=d)
+    else:
+        wt = torch.randn(co, ci, k, k, generator=g) * 0.1
+        ref_fn = lambda a, b: F.conv2d(a, b, stride=s, padding=p, dilation=d)
+        our_fn = lambda a, b: conv2d_gradfix.conv2d(a, b, stride=s, padding=p, dilation=d)
+    v = torch.randn(ref_fn(x, wt).shape, generator=g)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        xr, wr = x.to(dtype).float().requires_grad_(True), wt.to(dtype).float().requires_grad_(True)
+        vq = v.to(dtype).float()
+        want, = torch.autograd.grad((ref_fn(xr, wr) * vq).sum(), [wr])
+        xq, wq = x.to(dtype).to(dev).requires_grad_(True), wt.to(dtype).to(dev).requires_grad_(True)
+        got, = torch.autograd.grad((our_fn(xq, wq).float() * vq.to(dev)).sum(), [wq])
+        assert got.dtype == dtype and got.shape == wt.shape
+        err = float((got.float().cpu() - want).abs().max() / want.abs().max())
+        assert err < tol, (case, dtype, err)

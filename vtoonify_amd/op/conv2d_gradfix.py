@@ -11,17 +11,19 @@ Autograd follows the reference's structure (op/conv2d_gradfix.py:134-223), every
 same HIP kernel family:
   grad_input   = the opposite convolution of grad_output with the weight (conv <-> conv_transpose,
                  output_padding from the shapes, :122-132), itself differentiable;
-  grad_weight  = Conv2dGradWeight (honours `weight_gradients_disabled`): the batch axis becomes the
-                 contraction axis -- dW[co,ci] = conv2d(x^T (Ci,N,H,W), g^T (Co,N,Ho,Wo) as filters,
-                 stride = dilation, dilation = stride)[:, :, :kh, :kw] -- where the reference calls
+  grad_weight  = Conv2dGradWeight (honours `weight_gradients_disabled`): the pixels are the contraction
+                 axis -- dW = A B^T with A = the kh*kw shifted views of the input, B = grad_output, K = N*Ho*Wo,
+                 as one split-K 1x1 contraction (_grad_weight_kernel) -- where the reference calls
                  cudnn_convolution_backward_weight; its backward gives the second-order terms
                  (R1 / path-length regularisers, util.py:75-82);
   grad_bias    = grad_output.sum((0, 2, 3)).
 """
 import contextlib
+import ctypes as C
 
 import torch
 
+from .. import _lib
 from .. import kernels as K
 
 enabled = True
@@ -120,14 +122,66 @@ def _output_padding(cfg, input_shape, output_shape, weight_shape):
                  - dilation * (weight_shape[i + 2] - 1) for i in range(2))
 
 
+_GW_CHUNK_BYTES = 1 << 30   # one im2col operand per GEMM launch stays below this (32-bit buffer ranges of the kernels)
+
+
 def _grad_weight_kernel(inp, grad, kh, kw, stride, padding, dilation):
     """dW[c_grad, c_inp, ky, kx] = sum_{n,oy,ox} grad[n,c_grad,oy,ox] * inp[n,c_inp,oy*s+ky*d-p,ox*s+kx*d-p]
-    as ONE forward contraction with the batch as the contraction axis."""
-    y = _launch(inp.transpose(0, 1).contiguous(), grad.transpose(0, 1).contiguous(), None, dilation, padding,
-                stride, 1, False, 0)
-    if y.shape[2] < kh or y.shape[3] < kw:
+    (what the reference gets from cudnn_convolution_backward_weight, op/conv2d_gradfix.py:188-223).
+
+    The PIXELS are the contraction axis: with A[(tap, c_inp)][(n,oy,ox)] = the tap's shifted, strided view of the
+    zero-padded input (kh*kw strided device copies -- data movement only) and B[c_grad][(n,oy,ox)] = grad, dW = A B^T is a
+    GEMM with K = N*Ho*Wo.  It runs as a 1x1 convolution of the MFMA kernels over an "image" of kh*kw*C_inp pixels with
+    N*Ho*Wo channels, split along K over the whole GPU (fp32 slices summed in slice order: deterministic), fp32 out.
+    (Round 1-4 form: the batch as the channel axis of a conv with an Ho x Wo "filter" -- 4 of 32 K lanes of every MFMA
+    used and one K step per filter tap: 11.3 ms for a 128->128 3x3 layer at 4 x 256^2 in bf16, profiles/r05_grad_bench.json.)
+    Batches too large for one operand are cut into groups of images / rows; their fp32 partial results are added."""
+    n, ca, h, w = inp.shape
+    n2, cb, ho, wo = grad.shape
+    s, p, d = stride, padding, dilation
+    if n2 != n or (ho - 1) * s + (kh - 1) * d + 1 > h + 2 * p or (wo - 1) * s + (kw - 1) * d + 1 > w + 2 * p:
         raise ValueError("conv2d_gradfix: inconsistent shapes in the weight gradient")
-    return y[:, :, :kh, :kw].transpose(0, 1).contiguous()
+    dtype, dev = inp.dtype, inp.device
+    esz = 4 if dtype == torch.float32 else 2
+    taps = kh * kw
+    m = taps * ca
+    xp = torch.nn.functional.pad(inp.detach(), (p, p, p, p)).transpose(0, 1)     # (Ca, N, Hp, Wp) view
+    gt = grad.detach().transpose(0, 1)                                            # (Cb, N, Ho, Wo) view
+    # groups of (images, output rows) whose operands fit the chunk size
+    per_row = max(m, cb) * wo * esz
+    if per_row * ho <= _GW_CHUNK_BYTES:
+        step = max(1, _GW_CHUNK_BYTES // (per_row * ho))
+        groups = [(i, min(n, i + step), 0, ho) for i in range(0, n, step)]
+    else:
+        rstep = max(1, _GW_CHUNK_BYTES // per_row)
+        groups = [(i, i + 1, y, min(ho, y + rstep)) for i in range(n) for y in range(0, ho, rstep)]
+    lib = _lib.lib()
+    acc = None
+    for n0, n1, y0, y1 in groups:
+        ni, rows = n1 - n0, y1 - y0
+        k = ni * rows * wo
+        kp = (k + 63) // 64 * 64                                                  # whole K steps of either dtype
+        a = torch.empty((taps, ca, kp), dtype=dtype, device=dev)
+        if kp != k:
+            a[:, :, k:].zero_()
+        for ky in range(kh):
+            for kx in range(kw):
+                r0, c0 = ky * d + y0 * s, kx * d
+                a[ky * kw + kx, :, :k].unflatten(1, (ni, rows, wo)).copy_(
+                    xp[:, n0:n1, r0:r0 + s * (rows - 1) + 1:s, c0:c0 + s * (wo - 1) + 1:s])
+        b = gt[:, n0:n1, y0:y1].reshape(cb, k, 1, 1).to(torch.float32).contiguous()
+        wp = K.pack_conv_weight(b, cin_dst=kp, out_dtype=dtype)
+        out = torch.empty((1, cb, 1, m), dtype=torch.float32, device=dev)
+        kwargs = dict(src0=a, c0=kp, ld0=kp, n=1, h=1, w=m, out_h=1, out_w=m, weight=wp, cout=cb, kh=1, kw=1, out=out,
+                      ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, dtype=K.dt_code(dtype))
+        need = int(lib.vt_conv2d_ws_bytes(C.byref(K.make_conv_desc(**kwargs))))
+        if need < 0:
+            raise _lib.VtError(f"vt_conv2d descriptor rejected: {lib.vt_last_error().decode()}")
+        ws = torch.zeros((need,), dtype=torch.uint8, device=dev) if need else None
+        K.conv2d(splitk_ws=ws, **kwargs)
+        acc = out if acc is None else acc + out
+    dw = acc.view(cb, kh, kw, ca).permute(0, 3, 1, 2).contiguous()
+    return dw if dtype == torch.float32 else dw.to(dtype)
 
 
 class _Conv(torch.autograd.Function):
