@@ -163,8 +163,14 @@ def test_layout_change_at_the_model_boundary(dev, odt):
     """vt_nchw_to_nhwc: exact (a cast and a transpose), pad channels zero, rows wider than the padded channel count untouched.
     Narrow tensors (the 22-channel frame) take the one-thread-per-pixel kernel, wide ones the (pixel, 8-channel group) form."""
     g = np.random.default_rng(3)
-    for n, c, h, w, ld in ((2, 22, 9, 13, 32), (1, 3, 5, 7, None), (2, 32, 4, 6, None), (1, 40, 3, 5, 48), (3, 19, 8, 8, 24)):
+    for n, c, h, w, ld, idt in ((2, 22, 9, 13, 32, None), (1, 3, 5, 7, None, None), (2, 32, 4, 6, None, None), (1, 40, 3, 5, 48, None),
+                                (3, 19, 8, 8, 24, None),
+                                # wide tensors: 64-pixel x 64-channel tiles through LDS (ragged pixel and channel tails, several tiles)
+                                (2, 128, 9, 13, None, None), (1, 324, 5, 7, 336, None), (2, 70, 8, 9, 72, torch.bfloat16),
+                                (1, 64, 70, 3, None, torch.bfloat16), (2, 130, 11, 12, 144, None)):
         x = T(g.standard_normal((n, c, h, w)).astype(np.float32), dev)
+        if idt is not None:
+            x = x.to(idt)
         cpad = (c + 7) // 8 * 8
         ldo = ld or cpad
         out = torch.full((n, h, w, ldo), 7.0, dtype=odt, device=dev)
@@ -173,6 +179,20 @@ def test_layout_change_at_the_model_boundary(dev, odt):
         want[..., :cpad] = 0
         want[..., :c] = x.cpu().permute(0, 2, 3, 1).to(odt)
         assert torch.equal(out.cpu(), want), (n, c, h, w, ld)
+
+
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_layout_change_back_to_planes(dev, odt):
+    """vt_nhwc_to_nchw: exact (a cast and a transpose) for rows wider than the channel count; channel counts that are a multiple
+    of 8 (>= 32) go through the LDS tiles, the others through the one-thread-per-element form."""
+    g = np.random.default_rng(4)
+    for n, c, h, w, ld, idt in ((2, 19, 8, 8, 24, torch.float32), (1, 3, 5, 7, 8, torch.bfloat16), (2, 128, 9, 13, 128, torch.bfloat16),
+                                (1, 64, 70, 3, 72, torch.float32), (2, 72, 8, 9, 80, torch.bfloat16), (1, 136, 11, 12, 136, torch.float32),
+                                (1, 32, 4, 6, 32, torch.float32), (1, 40, 6, 5, 44, torch.float32)):   # (ld 44 fp32: rows stay 16-byte aligned)
+        x = T(g.standard_normal((n, h, w, ld)).astype(np.float32), dev).to(idt)
+        y = K.nhwc_to_nchw(x, ld, n, c, h, w, idt, odt, x.device, x)
+        want = x.cpu()[..., :c].permute(0, 3, 1, 2).to(odt)
+        assert torch.equal(y.cpu(), want), (n, c, h, w, ld, idt)
 
 
 def test_mfma_lane_maps(dev):
@@ -974,6 +994,33 @@ def test_conv2d_gradfix_autograd(dev):
     with op.conv2d_gradfix.no_weight_gradients():
         gx, gw = torch.autograd.grad(op.conv2d_gradfix.conv2d(x, w, padding=1).sum(), (x, w), allow_unused=True)
     assert gx is not None and gw is None
+
+
+def test_conv2d_gradfix_autograd_wide_channels(dev):
+    """The same with >= 32 output channels per group: NHWC out of the fast epilogues + the tiled vt_nhwc_to_nchw, and
+    conv_transpose2d(stride 1) -- every stride-1 grad_input -- as a convolution with the turned kernel."""
+    assert _gradfix_case(dev, False, 2, 32, 9, 7, 40, 3, 1, 1, 1, seed=10) < F32_TOL
+    assert _gradfix_case(dev, False, 1, 16, 10, 9, 32, 3, 2, 1, 1, seed=11) < F32_TOL          # stride 2
+    assert _gradfix_case(dev, False, 1, 32, 9, 9, 32, 3, 1, 2, 2, seed=12) < F32_TOL           # dilation 2
+    assert _gradfix_case(dev, True, 2, 32, 6, 5, 32, 3, 1, 1, 1, seed=13) < F32_TOL            # transposed, stride 1
+    assert _gradfix_case(dev, True, 1, 16, 5, 4, 32, 3, 2, 0, 1, seed=14) < F32_TOL            # transposed, stride 2
+    assert _gradfix_case(dev, False, 2, 16, 6, 6, 64, 3, 1, 1, 1, groups=2, seed=15) < F32_TOL  # groups: 32 channels each
+    assert _gradfix_case(dev, False, 1, 32, 8, 8, 32, 1, 1, 0, 1, seed=16) < F32_TOL           # 1x1
+    # bf16 tensors: forward and first-order gradients against the same graph on the bf16-rounded operands in fp32
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(2, 32, 8, 7, generator=g).bfloat16()
+    w0 = (torch.randn(40, 32, 3, 3, generator=g) / 17).bfloat16()
+    go = torch.randn(2, 40, 8, 7, generator=g).bfloat16()
+    x, w = x0.to(dev).requires_grad_(True), w0.to(dev).requires_grad_(True)
+    y = op.conv2d_gradfix.conv2d(x, w, padding=1)
+    gx, gw = torch.autograd.grad(y, (x, w), go.to(dev))
+    xr, wr = x0.float().requires_grad_(True), w0.float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1)
+    rx, rw = torch.autograd.grad(yr, (xr, wr), go.float())
+    assert y.dtype == torch.bfloat16 and gx.dtype == torch.bfloat16 and gw.dtype == torch.bfloat16
+    for a, r in ((y, yr), (gx, rx), (gw, rw)):
+        assert rel_err(a.detach().float().cpu().numpy(), r.detach().numpy()) < 1.2e-2
 
 
 # ---------------------------------------------------------------- style ops / norm / glue

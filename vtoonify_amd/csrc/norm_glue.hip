@@ -531,6 +531,86 @@ nhwc_to_nchw_kernel(TO* __restrict__ out, const TI* __restrict__ in, int ld_in, 
     }
 }
 
+// Wide tensors (the stand-alone convolutions of conv2d_gradfix, RAFT's correlation features): a 64-pixel x 64-channel tile per
+// workgroup goes through LDS, so that BOTH sides of the copy move whole segments -- a wavefront reads 64 consecutive pixels of a
+// plane (128 / 256 bytes) and 8 lanes write the 64 channels of one pixel (128 / 256 bytes).  The one-thread-per-(pixel, 8 channels)
+// forms above and below leave one side at 16 bytes per 256-byte row (nchw_to_nhwc_kernel's stores) or at one element per row
+// (nhwc_to_nchw_kernel's loads): profiles/r05_grad_bench.json, where a 128-channel 4 x 256^2 conv of the operator surface spent
+// more time in its two layout changes than in its contraction.  Exact copies (or the same round-to-nearest-even as those forms).
+constexpr int TR_P = 64, TR_C = 64;
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_tile_kernel(TO* __restrict__ out, int ld_out, const TI* __restrict__ in, int n, int c, int hw, int cpad) {
+    constexpr int VEC = 16 / (int)sizeof(TO);
+    __shared__ float tile[TR_C][TR_P + 1];
+    const int ptiles = (hw + TR_P - 1) / TR_P, ctiles = (cpad + TR_C - 1) / TR_C;
+    const int64_t total = (int64_t)n * ptiles * ctiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = threadIdx.x & 7;
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int ct = (int)(t % ctiles);
+        const int64_t r = t / ctiles;
+        const int pt = (int)(r % ptiles), img = (int)(r / ptiles);
+        const int p0 = pt * TR_P, c0 = ct * TR_C;
+        for (int k = wave; k < TR_C; k += 4) {   // planes -> LDS (channels >= c read as zero: the padding of the rows)
+            const int ch = c0 + k, p = p0 + lane;
+            tile[k][lane] = (ch < c && p < hw) ? to_f32(in[((int64_t)img * c + ch) * hw + p]) : 0.0f;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x >> 3; q < TR_P; q += 32) {   // LDS -> pixel rows
+            const int p = p0 + q, ch = c0 + g * 8;
+            if (p < hw && ch < cpad) {
+                float f[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[k] = tile[g * 8 + k][q];
+                TO* o = out + ((int64_t)img * hw + p) * ld_out + ch;
+#pragma unroll
+                for (int v = 0; v < 8 / VEC; ++v) st128(o + v * VEC, pack16<TO>(f + v * VEC));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_tile_kernel(TO* __restrict__ out, const TI* __restrict__ in, int ld_in, int n, int c, int hw) {
+    constexpr int VEC = 16 / (int)sizeof(TI);
+    __shared__ float tile[TR_C][TR_P + 1];
+    const int ptiles = (hw + TR_P - 1) / TR_P, ctiles = (c + TR_C - 1) / TR_C;
+    const int64_t total = (int64_t)n * ptiles * ctiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = threadIdx.x & 7;
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int ct = (int)(t % ctiles);
+        const int64_t r = t / ctiles;
+        const int pt = (int)(r % ptiles), img = (int)(r / ptiles);
+        const int p0 = pt * TR_P, c0 = ct * TR_C;
+        for (int q = threadIdx.x >> 3; q < TR_P; q += 32) {   // pixel rows -> LDS (c % 8 == 0: whole 8-channel groups)
+            const int p = p0 + q, ch = c0 + g * 8;
+            if (p < hw && ch < c) {
+                float f[8];
+                const TI* src = in + ((int64_t)img * hw + p) * ld_in + ch;
+#pragma unroll
+                for (int v = 0; v < 8 / VEC; ++v) unpack16<TI>(ld128(src + v * VEC), f + v * VEC);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tile[g * 8 + k][q] = f[k];
+            }
+        }
+        __syncthreads();
+        for (int k = wave; k < TR_C; k += 4) {   // LDS -> planes
+            const int ch = c0 + k, p = p0 + lane;
+            if (ch < c && p < hw) out[((int64_t)img * c + ch) * hw + p] = from_f32<TO>(tile[k][lane]);
+        }
+        __syncthreads();
+    }
+}
+
+inline unsigned tile_grid(int n, int hw, int cc) {
+    int64_t b = (int64_t)n * ((hw + TR_P - 1) / TR_P) * ((cc + TR_C - 1) / TR_C);
+    if (b > 16384) b = 16384;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
 // ---------------------------------------------------------------------------------
 // pSp encoder glue (model/encoder/encoders/helpers.py:53-119, psp_encoders.py:71-88)
 // ---------------------------------------------------------------------------------
@@ -743,6 +823,18 @@ static int nchw_to_nhwc_out(void* out, int ld_out, const TI* in, int n, int c, i
 #undef VT_PIX
         return vt_check_launch("vt_nchw_to_nhwc");
     }
+    if (cpad > 32 && (out_dtype == VT_F32 || out_dtype == VT_BF16) && ((int64_t)ld_out * osz) % 16 == 0 &&
+        (uintptr_t)out % 16 == 0) {   // wide tensors: tiles through LDS
+        const unsigned grid = tile_grid(n, hw, cpad);
+        if (out_dtype == VT_F32) {
+            auto k = nchw_to_nhwc_tile_kernel<TI, float>;
+            VT_LAUNCH(k, dim3(grid), dim3(256), stream, (float*)out, ld_out, in, n, c, hw, cpad);
+        } else {
+            auto k = nchw_to_nhwc_tile_kernel<TI, bf16_t>;
+            VT_LAUNCH(k, dim3(grid), dim3(256), stream, (bf16_t*)out, ld_out, in, n, c, hw, cpad);
+        }
+        return vt_check_launch("vt_nchw_to_nhwc");
+    }
     if (out_dtype == VT_F32) {
         auto k = nchw_to_nhwc_kernel<TI, float>;
         VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, ld_out, in, n, c, hw, cpad);
@@ -771,6 +863,18 @@ template <typename TI>
 static int nhwc_to_nchw_out(void* out, const TI* in, int ld_in, int n, int c, int hw, int out_dtype,
                             vt_stream stream) {
     const int64_t total = (int64_t)n * c * hw;
+    if (c >= 32 && c % 8 == 0 && (out_dtype == VT_F32 || out_dtype == VT_BF16) &&
+        ((int64_t)ld_in * (int64_t)sizeof(TI)) % 16 == 0 && (uintptr_t)in % 16 == 0) {   // wide tensors: tiles through LDS
+        const unsigned grid = tile_grid(n, hw, c);
+        if (out_dtype == VT_F32) {
+            auto k = nhwc_to_nchw_tile_kernel<TI, float>;
+            VT_LAUNCH(k, dim3(grid), dim3(256), stream, (float*)out, in, ld_in, n, c, hw);
+        } else {
+            auto k = nhwc_to_nchw_tile_kernel<TI, bf16_t>;
+            VT_LAUNCH(k, dim3(grid), dim3(256), stream, (bf16_t*)out, in, ld_in, n, c, hw);
+        }
+        return vt_check_launch("vt_nhwc_to_nchw");
+    }
     if (out_dtype == VT_F32) {
         auto k = nhwc_to_nchw_kernel<TI, float>;
         VT_LAUNCH(k, dim3(grid_for(total)), dim3(256), stream, (float*)out, in, ld_in, n, c, hw);

@@ -87,29 +87,46 @@ def _launch(input, weight, bias, stride, padding, dilation, groups, transposed, 
         raise ValueError("convolution output would be empty")
     cin_g = cin // groups
     cpad = (cin_g + 7) // 8 * 8
-    out = torch.empty((n, cout, out_h, out_w), dtype=torch.float32, device=input.device)
     w32 = weight.detach().to(torch.float32).contiguous()
     b32 = bias.detach().to(torch.float32).contiguous() if bias is not None else None
     x = input.detach().contiguous()
+    # conv_transpose2d with stride 1 IS a convolution with the kernel turned by 180 degrees and the channel axes swapped
+    # (padding d*(k-1) - p): it takes the patch kernels of the forward pass instead of the gather form -- this is the
+    # grad_input of every stride-1 convolution (op/conv2d_gradfix.py:147-160 in the reference).  Data movement on the weight only.
+    as_conv = transposed and stride == 1 and oph == 0 and opw == 0 and dilation * (kh - 1) - padding >= 0 and kh == kw
+    conv_pad = dilation * (kh - 1) - padding if as_conv else padding
+    # wide outputs: NHWC out of the fast epilogues + one tiled layout change (vt_nhwc_to_nchw); narrow ones (ToRGB, masks)
+    # keep the planar output of the thin kernels
+    via_nhwc = cout_g >= 32 and cout_g % 8 == 0
+    out = torch.empty((n, cout, out_h, out_w), dtype=(dtype if via_nhwc else torch.float32), device=input.device)
     for g in range(groups):
         xg = x[:, g * cin_g:(g + 1) * cin_g].contiguous() if groups > 1 else x
         x_nhwc = K.nchw_to_nhwc(xg, dtype, ld_out=cpad)
         if transposed:
             wg = w32[g * cin_g:(g + 1) * cin_g].contiguous() if groups > 1 else w32
-            wp = K.pack_conv_weight(wg, cin_dst=cpad, src_transposed=True, out_dtype=dtype)
+            if as_conv:
+                wp = K.pack_conv_weight(wg.flip(2, 3).transpose(0, 1).contiguous(), cin_dst=cpad, out_dtype=dtype)
+            else:
+                wp = K.pack_conv_weight(wg, cin_dst=cpad, src_transposed=True, out_dtype=dtype)
         else:
             wg = w32[g * cout_g:(g + 1) * cout_g].contiguous() if groups > 1 else w32
             wp = K.pack_conv_weight(wg, cin_dst=cpad, out_dtype=dtype)
-        og = out if groups == 1 else torch.empty((n, cout_g, out_h, out_w), dtype=torch.float32,
-                                                 device=input.device)
-        K.conv2d(src0=x_nhwc, c0=cpad, ld0=cpad, n=n, h=h, w=w, out_h=out_h, out_w=out_w, weight=wp,
-                 cout=cout_g, kh=kh, kw=kw, stride=stride, pad=padding, dil=dilation,
-                 transposed=int(transposed), bias=(b32[g * cout_g:(g + 1) * cout_g].contiguous()
-                                                   if b32 is not None else None),
-                 out=og, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, dtype=K.dt_code(dtype))
+        bg = b32[g * cout_g:(g + 1) * cout_g].contiguous() if b32 is not None else None
+        common = dict(src0=x_nhwc, c0=cpad, ld0=cpad, n=n, h=h, w=w, out_h=out_h, out_w=out_w, weight=wp, cout=cout_g, kh=kh,
+                      kw=kw, stride=stride, pad=conv_pad, dil=dilation, transposed=int(transposed and not as_conv), bias=bg,
+                      dtype=K.dt_code(dtype))
+        if via_nhwc:
+            o_nhwc = torch.empty((n, out_h, out_w, cout_g), dtype=dtype, device=input.device)
+            K.conv2d(out=o_nhwc, ld_out=cout_g, **common)
+            og = K.nhwc_to_nchw(o_nhwc, cout_g, n, cout_g, out_h, out_w, dtype, dtype, input.device, o_nhwc)
+        else:
+            og = out if groups == 1 else torch.empty((n, cout_g, out_h, out_w), dtype=torch.float32, device=input.device)
+            K.conv2d(out=og, ld_out=0, out_layout=K.OUT_NCHW, out_dtype=K.VT_F32, **common)
         if groups > 1:
             out[:, g * cout_g:(g + 1) * cout_g] = og
-    return out if dtype == torch.float32 else out.to(dtype)
+        elif via_nhwc:
+            out = og
+    return out if out.dtype == dtype else out.to(dtype)
 
 
 def _output_padding(cfg, input_shape, output_shape, weight_shape):
