@@ -156,6 +156,21 @@ def op_surface(dev, iters=10):
                       "frac": round(nb / us / 1e3 / PEAK_HBM_GBS, 4)} for n, us, nb in rows]}
 
 
+def end_to_end(backbone, H, W, frames_per_step, step_s, dtype):
+    dual = backbone == "dualstylegan"
+    px = H * W / 65536.0
+    gflop = (459.1 if dual else 400.5) * px
+    act_m, w_m = ((1005.5, 98.2) if dual else (876.3, 59.4))
+    esz = 2 if dtype == "bf16" else 4
+    gbytes = (act_m * px + w_m) * esz / 1e3
+    tf = gflop * frames_per_step / step_s / 1e3
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else (PEAK_F32X3_TFLOPS if dtype == "fp32x3" else PEAK_F32_TFLOPS)
+    return {"gflop_per_frame": round(gflop, 1), "gbyte_per_frame": round(gbytes, 3), "tflops": round(tf, 1),
+            "frac_of_mfma_peak": round(tf / peak, 4), "hbm_gbs": round(gbytes * frames_per_step / step_s, 1),
+            "frac_of_hbm_peak": round(gbytes * frames_per_step / step_s / PEAK_HBM_GBS, 4),
+            "what": "SURVEY.md 8(d) algorithmic FLOPs and op-granularity bytes of the whole step / wall time of the step"}
+
+
 def kernel_table(eng, plan, dtype, iters, emu=False, want_ops=False, peak_tf=None):
     """Per-kernel-class table of one frame (HIP events on the launch stream around every launch, engine.time_ops)
     and the `roofline` object of the class with the largest share of GPU time.  `peak_tf` overrides the matrix peak the
@@ -182,7 +197,7 @@ def kernel_table(eng, plan, dtype, iters, emu=False, want_ops=False, peak_tf=Non
         # which roof bounds this kernel: compare its arithmetic intensity with the ridge
         ai = c["flops"] / max(c["bytes"], 1)
         bound = "mfma" if ai > peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-        rows.append({"kernel": name, "launches": c["launches"], "ms_per_frame": c["ms"],
+        rows.append({"kernel": name, "launches": c["launches"], "ms_per_step": c["ms"],
                      "share": c["ms"] / frame_ms if frame_ms else 0.0,
                      "avg_launch_us": 1e3 * c["ms"] / c["launches"], "bound": bound,
                      "tflops": tf, "gbs": gbs,
@@ -202,9 +217,9 @@ def kernel_table(eng, plan, dtype, iters, emu=False, want_ops=False, peak_tf=Non
     roofline["timing"] = "hipEvent pair per launch minus half the empty-pair gap"
     roofline["event_gap_us"] = 1e3 * getattr(eng, "event_gap_ms", 0.0)
     roofline["kernel_sum_ms_raw"] = sum(getattr(eng, "last_raw_ms", []))
-    roofline.update({"kernel": dom["kernel"], "launches_per_frame": dom["launches"],
-                     "avg_launch_us": dom["avg_launch_us"], "share_of_frame": dom["share"],
-                     "kernel_sum_ms_per_frame": frame_ms})
+    roofline.update({"kernel": dom["kernel"], "launches_per_step": dom["launches"],
+                     "avg_launch_us": dom["avg_launch_us"], "share_of_step": dom["share"],
+                     "kernel_sum_ms_per_step": frame_ms})
     return (rows, roofline, per_op) if want_ops else (rows, roofline)
 
 
@@ -322,6 +337,11 @@ def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
         return real
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
             "backend": getattr(O, "BACKEND", "numpy"),
+            "restates": "model/stylegan/op_cpu/upfirdn2d.py:20-60, op_cpu/fused_act.py:23-34, model/stylegan/model.py:259-306 "
+                        "(ModulatedConv2d, fused branch), :32-90 (Blur / Upsample), model/dualstylegan.py:6-45, "
+                        "model/vtoonify.py:92-128,210-277 -- the reference tree is not mounted on this box, so its own op_cpu "
+                        "path cannot be timed here (kind stays \"port\")",
+            "cpu_branch": cpu_branch_rate(backbone, h, w, height, width, cores),
             "repetitions_s": [round(t, 3) for t in reps],
             "port_vs_reference": "profiles/r04_cpu_port_vs_reference.txt (authoring container, 8 idle cores, alternating): the "
                                  "reference's own op_cpu path (model/vtoonify.py:210-277 over model/stylegan/op_cpu) 1.72 s per frame, this "
@@ -329,6 +349,29 @@ def cpu_baseline(backbone: str, height: int, width: int, budget_s: float):
             "sample": f"1 frame 22x{h}x{w} -> 3x{4 * h}x{4 * w} fp32 through oracle/vtoonify_oracle.py, median of "
                       f"{len(reps)} runs = {dt:.2f} s, scaled x{(height * width) // (h * w)} in pixels to the "
                       f"22x{height}x{width} workload"}
+
+
+def cpu_branch_rate(backbone, h, w, height, width, cores):
+    """The drop-in's own CPU-tensor path (`style_transfer.py --cpu`: vtoonify_amd/eager.py over op/native.py -- the reference's
+    eager operator sequence on F.conv2d / F.conv_transpose2d, i.e. the same torch calls its op_cpu path makes) on the same
+    sample and cores, reported BESIDE the oracle's time, never as the baseline value."""
+    try:
+        from vtoonify_amd import _lib, synth
+        from vtoonify_amd.eager import EagerVToonify
+        if _lib.emulation_injected():
+            return None
+        sd = synth.synth_state_dict(state_shapes(backbone), 0)
+        net = EagerVToonify(sd, backbone, 256)
+        x, s = synth.synth_frames(1, h, w, seed=2), synth.synth_style(seed=17)
+        with torch.no_grad():
+            net.forward(x[:, :, :64, :64].contiguous(), s, 0.5)   # warm-up
+            t0 = time.perf_counter()
+            net.forward(x, s, 0.5)
+            dt = time.perf_counter() - t0
+        return {"value": 1.0 / (dt * (height * width) / (h * w)), "unit": "frames/s", "cores": cores, "seconds": round(dt, 3),
+                "what": f"vtoonify_amd.eager.EagerVToonify on CPU tensors (the module's --cpu path), 1 frame 22x{h}x{w}, one run"}
+    except Exception as e:   # an extra: never lose the line over it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def pin_to_gpu_numa_node(local_rank: int, ws: int):
@@ -670,7 +713,7 @@ def main():
         rows, roofline, per_op = kernel_table(eng, plan, dtype, max(1, args.op_iters), emu=emu, want_ops=True)
         if args.kernels:
             for r in rows:
-                print(f"{r['kernel']:<36} n={r['launches']:3d} {r['ms_per_frame']:8.3f} ms {100 * r['share']:5.1f}% "
+                print(f"{r['kernel']:<36} n={r['launches']:3d} {r['ms_per_step']:8.3f} ms {100 * r['share']:5.1f}% "
                       f"{r['bound']:>4} {r['tflops']:8.1f} TF/s {r['gbs']:8.1f} GB/s frac {r['frac']:.3f}",
                       file=sys.stderr)
             for info, ms in per_op:
@@ -700,6 +743,10 @@ def main():
                        "weight_broadcast_s": t_bcast, "host": host,
                        "per_rank_frames_per_s": fps / ws},
             "roofline": roofline,
+            # the whole step against the chip: algorithmic FLOPs / bytes of SURVEY.md 8(d) (D 459.1 GFLOP, 2.21 GB bf16 per
+            # 22x256x256 frame; T 400.5 / 1.87; x H*W/65536) over the wall time of the step -- a sanity bound (nothing skipped,
+            # nothing above a peak), not the roofline claim, which is per kernel
+            "end_to_end": end_to_end(args.backbone, H, W, B * ws, 1e-3 * (1e3 * elapsed / args.steps), args.dtype),
             "single_stream": single,
             "module_call": module_call,
             **extras,
@@ -744,7 +791,7 @@ def main():
             "pipeline": _v(r, "pipeline", "value"), "cpu_baseline": (round(r["cpu_baseline"]["value"], 3), r["cpu_baseline"]["kind"])
             if r.get("cpu_baseline") else None,
             "roofline": [r["roofline"]["kernel"], round(r["roofline"]["avg_launch_us"], 1), round(r["roofline"]["frac"], 3)],
-            "kernel_sum_ms": round(r["roofline"]["kernel_sum_ms_per_frame"], 3), "launches": len(per_op) if rank == 0 else None,
+            "kernel_sum_ms": round(r["roofline"]["kernel_sum_ms_per_step"], 3), "launches": len(per_op) if rank == 0 else None,
         }.items() if v is not None}
         print(json.dumps(result))
     if dist.is_initialized():

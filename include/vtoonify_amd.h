@@ -42,7 +42,12 @@ enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2,
         * accumulate; ~4e-5 of max|y| end to end against fp32).  The reference's fp32 convolutions (cuDNN behind
         * op/conv2d_gradfix.py:34-42, F.conv2d in model/vtoonify.py:92-128) at matrix-core speed; kernel instances without
         * that form run exact fp32.  out_dtype stays VT_F32 / VT_BF16. */
-       VT_F32X3 = 3 };
+       VT_F32X3 = 3,
+       /* vt_upfirdn2d / vt_fused_bias_act only: double tensors AND double arithmetic -- the reference's native ops are
+        * dispatched over AT_DISPATCH_FLOATING_TYPES_AND_HALF (upfirdn2d_kernel.cu:311, fused_bias_act_kernel.cu:96), which
+        * includes double.  The path never uses it; one plain kernel per op, no tiling.  With VT_F64 the `fir` argument of
+        * vt_upfirdn2d points at DOUBLE taps (the reference hands kernel.data_ptr<scalar_t>()). */
+       VT_F64 = 4 };
 enum { VT_OK = 0, VT_ERR_ARG = 1, VT_ERR_UNSUPPORTED = 2, VT_ERR_LAUNCH = 3 };
 
 /* activation codes of the fused epilogues */
@@ -63,7 +68,7 @@ const char* vt_build_target(void);
  * Python side folds N*C into planes exactly like op/upfirdn2d.py:100 with minor=1);
  * `fir` is the un-flipped (kh, kw) fp32 kernel (the flip of upfirdn2d_kernel.cu:137 is
  * applied inside).  out_h/out_w follow op/upfirdn2d.py:104-105 and are returned by
- * vt_upfirdn2d_out_size.  dtype: VT_F32 / VT_BF16 / VT_F16 (fp32 accumulate).
+ * vt_upfirdn2d_out_size.  dtype: VT_F32 / VT_BF16 / VT_F16 (fp32 accumulate), VT_F64 (double taps, double accumulate).
  * --------------------------------------------------------------------------------- */
 int vt_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_y,
                           int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,

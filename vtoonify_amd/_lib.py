@@ -17,6 +17,7 @@ DEFAULT_LIB = os.path.join(HERE, "lib", "libvtoonify_amd.so")
 
 ABI_VERSION = 5   # VT_ABI_VERSION of include/vtoonify_amd.h
 VT_F32, VT_BF16, VT_F16 = 0, 1, 2
+VT_F64 = 4     # vt_upfirdn2d / vt_fused_bias_act only: double tensors, taps and arithmetic (include/vtoonify_amd.h)
 VT_F32X3 = 3   # vt_conv_desc.dtype only: fp32 tensors, products as three bf16 MFMAs (include/vtoonify_amd.h)
 ACT_NONE, ACT_LRELU, ACT_RELU_TANH, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_NCHW = 0, 1
@@ -192,6 +193,20 @@ def lib_path():
 
 def is_emulation() -> bool:
     return lib().vt_build_target() != b"gfx950"
+
+
+def emulation_injected() -> bool:
+    """True only while a TEST has bound the host-emulation build with use_library().  Never loads anything: the operator
+    surface asks this to tell a CPU tensor that belongs to the emulation (tests) from a CPU tensor of a user, which takes
+    the native torch formula like the reference's own CPU branch (op/upfirdn2d.py:159-160, op/fused_act.py:105-116)."""
+    return _lib is not None and _lib.vt_build_target() != b"gfx950"
+
+
+def release_library():
+    """Forget the bound library (tests: leave the emulation); the next lib() binds the product library again."""
+    global _lib, _lib_path
+    _lib = None
+    _lib_path = None
 
 
 def check(rc: int, what: str = ""):

@@ -97,6 +97,27 @@ fba_flat_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restric
     }
 }
 
+// VT_F64 (fused_bias_act_kernel.cu:96 dispatches double too): double tensors, double arithmetic, same operation order.
+__global__ void __launch_bounds__(256)
+fba_flat_f64_kernel(double* __restrict__ out, const double* __restrict__ x, const double* __restrict__ bias,
+                    const double* __restrict__ refer, int64_t numel, int64_t step_b, int size_b, int mode,
+                    double alpha, double scale) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) {
+        double v = x[i];
+        if (bias) v += bias[(i / step_b) % size_b];
+        const double r = refer ? refer[i] : 0.0;
+        double y;
+        switch (mode) {
+            case 12: case 32: y = 0.0; break;
+            case 30: y = (v > 0.0) ? v : v * alpha; break;
+            case 31: y = (r > 0.0) ? v : v * alpha; break;
+            default: y = v; break;
+        }
+        out[i] = y * scale;
+    }
+}
+
 template <typename T>
 int launch_fba(void* out, const void* x, const void* bias, const void* refer, int64_t numel,
                int64_t step_b, int size_b, int mode, float alpha, float scale, vt_stream stream) {
@@ -152,6 +173,14 @@ extern "C" int vt_fused_bias_act(void* out, const void* x, const void* bias, con
             return launch_fba<bf16_t>(out, x, bias, refer, numel, step_b, size_b, mode, alpha, scale, stream);
         case VT_F16:
             return launch_fba<f16_t>(out, x, bias, refer, numel, step_b, size_b, mode, alpha, scale, stream);
+        case VT_F64: {
+            int64_t blocks = (numel + 255) / 256;
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            auto k = fba_flat_f64_kernel;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (double*)out, (const double*)x, (const double*)bias,
+                      (const double*)refer, numel, step_b, size_b, mode, (double)alpha, (double)scale);
+            return vt_check_launch("fused_bias_act(f64)");
+        }
     }
     vt_set_error("vt_fused_bias_act: unsupported dtype %d", dtype);
     return VT_ERR_UNSUPPORTED;

@@ -326,6 +326,38 @@ upfirdn2d_generic(T* __restrict__ out, const T* __restrict__ in, const float* __
     }
 }
 
+// VT_F64: the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (upfirdn2d_kernel.cu:311) includes double -- tensors, taps and
+// the accumulation are double there.  Off every path of the network; one output per lane, taps in (ky, kx) ascending order.
+__global__ void __launch_bounds__(256)
+upfirdn2d_generic_f64(double* __restrict__ out, const double* __restrict__ in, const double* __restrict__ fir,
+                      int64_t total, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                      int down_x, int down_y, int pad_x0, int pad_y0, int out_h, int out_w) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % out_w);
+        const int64_t t = idx / out_w;
+        const int oy = (int)(t % out_h);
+        const int64_t plane = t / out_h;
+        const double* src = in + plane * (int64_t)in_h * in_w;
+        const int Y0 = oy * down_y - pad_y0, X0 = ox * down_x - pad_x0;
+        double acc = 0.0;
+        for (int ky = posmod(-Y0, up_y); ky < kh; ky += up_y) {
+            const int Y = Y0 + ky;
+            if (Y < 0) continue;
+            const int iy = Y / up_y;
+            if (iy >= in_h) break;
+            for (int kx = posmod(-X0, up_x); kx < kw; kx += up_x) {
+                const int X = X0 + kx;
+                if (X < 0) continue;
+                const int ix = X / up_x;
+                if (ix >= in_w) break;
+                acc = fma(src[(int64_t)iy * in_w + ix], fir[(kh - 1 - ky) * kw + (kw - 1 - kx)], acc);
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
 template <typename T>
 int launch_upfirdn2d(void* out, const void* in, const float* fir, int64_t planes, int in_h,
                      int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
@@ -416,6 +448,16 @@ extern "C" int vt_upfirdn2d(void* out, const void* in, const float* fir, int64_t
         case VT_F16:
             return launch_upfirdn2d<f16_t>(out, in, fir, planes, in_h, in_w, kh, kw, up_x, up_y,
                                            down_x, down_y, pad_x0, pad_y0, out_h, out_w, stream);
+        case VT_F64: {
+            const int64_t total = planes * out_h * out_w;
+            int64_t blocks = (total + 255) / 256;
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            auto k = upfirdn2d_generic_f64;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, (double*)out, (const double*)in,
+                      reinterpret_cast<const double*>(fir), total, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y,
+                      pad_x0, pad_y0, out_h, out_w);
+            return vt_check_launch("upfirdn2d(f64)");
+        }
     }
     vt_set_error("vt_upfirdn2d: unsupported dtype %d", dtype);
     return VT_ERR_UNSUPPORTED;

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC, VT_BF16, VT_F16, VT_F32, VT_F32X3, ConvDesc
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU_TANH, OUT_NCHW, OUT_NHWC, VT_BF16, VT_F16, VT_F32, VT_F32X3, VT_F64, ConvDesc
 
 _DT = {torch.float32: VT_F32, torch.bfloat16: VT_BF16, torch.float16: VT_F16}
 
@@ -22,6 +22,12 @@ def dt_code(dtype: torch.dtype) -> int:
         return _DT[dtype]
     except KeyError:
         raise _lib.VtError(f"unsupported dtype {dtype}") from None
+
+
+def op_dt_code(dtype: torch.dtype) -> int:
+    """dtype code of the two native operators, which also take double like the reference's dispatch
+    (upfirdn2d_kernel.cu:311, fused_bias_act_kernel.cu:96: AT_DISPATCH_FLOATING_TYPES_AND_HALF)."""
+    return VT_F64 if dtype == torch.float64 else dt_code(dtype)
 
 
 def _dev_ok(*tensors):
@@ -54,8 +60,10 @@ def upfirdn2d_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1,
 
 
 def upfirdn2d_planes(x: torch.Tensor, fir: torch.Tensor, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
-    """x: (planes, in_h, in_w) contiguous; fir: (kh, kw) fp32 on the same device."""
+    """x: (planes, in_h, in_w) contiguous; fir: (kh, kw) fp32 (fp64 for an fp64 x) on the same device."""
     _dev_ok(x, fir)
+    if fir.dtype != (torch.float64 if x.dtype == torch.float64 else torch.float32):
+        raise _lib.VtError("upfirdn2d: FIR taps must be fp32 (fp64 for fp64 input)")
     planes, in_h, in_w = x.shape
     kh, kw = fir.shape
     oh, ow = upfirdn2d_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1)
@@ -63,7 +71,7 @@ def upfirdn2d_planes(x: torch.Tensor, fir: torch.Tensor, up_x, up_y, down_x, dow
         raise _lib.VtError(f"upfirdn2d: empty output ({oh} x {ow})")
     out = torch.empty((planes, oh, ow), dtype=x.dtype, device=x.device)
     _lib.check(_lib.lib().vt_upfirdn2d(_p(out), _p(x), _p(fir), planes, in_h, in_w, kh, kw, up_x, up_y,
-                                      down_x, down_y, px0, px1, py0, py1, dt_code(x.dtype), _stream(x)),
+                                      down_x, down_y, px0, px1, py0, py1, op_dt_code(x.dtype), _stream(x)),
                "vt_upfirdn2d")
     return out
 
@@ -76,7 +84,7 @@ def fused_bias_act(x, bias, refer, act, grad, alpha, scale):
         step_b *= int(s)
     size_b = int(bias.numel()) if bias is not None else 1
     _lib.check(_lib.lib().vt_fused_bias_act(_p(out), _p(x), _p(bias), _p(refer), x.numel(), step_b, size_b,
-                                           act, grad, float(alpha), float(scale), dt_code(x.dtype),
+                                           act, grad, float(alpha), float(scale), op_dt_code(x.dtype),
                                            _stream(x)), "vt_fused_bias_act")
     return out
 

@@ -4,7 +4,8 @@ module globals `enabled` / `weight_gradients_disabled`, `no_weight_gradients()`,
 
 On the reference every call ends in cuDNN via F.conv2d / F.conv_transpose2d; here GPU
 tensors run the MFMA implicit-GEMM kernel of libvtoonify_amd.so (fp32 inputs use the exact
-fp32 MFMA, bf16 inputs the bf16 MFMA).  `groups` (the per-sample trick of ModulatedConv2d,
+fp32 MFMA, bf16 inputs the bf16 MFMA); CPU tensors end in F.conv2d / F.conv_transpose2d like the
+reference's (its could_use_op() is False off the GPU, op/conv2d_gradfix.py:78-92).  `groups` (the per-sample trick of ModulatedConv2d,
 model.py:273-304) is a loop of launches.
 
 Autograd follows the reference's structure (op/conv2d_gradfix.py:134-223), every contraction on the
@@ -25,6 +26,7 @@ import torch
 
 from .. import _lib
 from .. import kernels as K
+from . import native
 
 enabled = True
 weight_gradients_disabled = False
@@ -252,6 +254,11 @@ class _ConvGradWeight(torch.autograd.Function):
 
 
 def _run(input, weight, bias, stride, padding, dilation, groups, transposed, output_padding):
+    if input.device.type == "cpu" and not _lib.emulation_injected():
+        # the reference's could_use_op() is False off the GPU: plain F.conv2d / F.conv_transpose2d (op/conv2d_gradfix.py:78-92)
+        if transposed:
+            return native.conv_transpose2d(input, weight, bias, stride, padding, output_padding, groups, dilation)
+        return native.conv2d(input, weight, bias, stride, padding, dilation, groups)
     _check(input, weight)
     needs_grad = torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or
                                               (bias is not None and bias.requires_grad))

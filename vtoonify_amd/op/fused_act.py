@@ -1,14 +1,18 @@
 """FusedLeakyReLU / fused_leaky_relu with the reference's surface
 (model/stylegan/op/fused_act.py:87-119): leaky_relu(x + bias[c], slope) * scale, bias
-broadcast on dim 1, any rank >= 2, new tensor returned.  GPU-only (the reference's CPU
-branch lives in its op_cpu package).  Backward uses the same kernel in its grad mode
+broadcast on dim 1, any rank >= 2, new tensor returned.  CPU tensors take the torch formula
+of op/native.py like the reference's own CPU branch (op/fused_act.py:105-116); GPU tensors run
+the gfx950 library or raise.  fp64 runs a double-arithmetic kernel (fused_bias_act_kernel.cu:96
+dispatches double too).  Backward uses the same kernel in its grad mode
 (fused_bias_act_kernel.cu:55-57 semantics), like op/fused_act.py:20-71.
 """
 import torch
 from torch import nn
 from torch.autograd import Function
 
+from .. import _lib
 from .. import kernels as K
+from . import native
 
 
 class _FusedLeakyReLUBackward(Function):
@@ -49,6 +53,10 @@ class _FusedLeakyReLU(Function):
 
 
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    if input.device.type == "cpu" and not _lib.emulation_injected():
+        if bias is not None and (input.ndim < 2 or bias.numel() != input.shape[1]):
+            raise ValueError("bias must have input.shape[1] elements")
+        return native.fused_leaky_relu(input, bias, float(negative_slope), float(scale))
     x = input.contiguous()  # op/fused_act.py:119
     b = None
     if bias is not None:

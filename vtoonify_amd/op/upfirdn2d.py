@@ -3,8 +3,10 @@
 (x, y), `pad` (p0, p1) or (x0, x1, y0, y1) with negative values cropping; returns a new
 (N, C, out_h, out_w) tensor of the input's dtype.
 
-The reference runs CPU tensors through a pure-torch formula; this package is GPU-only and
-raises instead (use the reference's op_cpu for CPU work).  Differentiable: the gradient is
+CPU tensors take a plain torch formula (op/native.py), as in the reference (op/upfirdn2d.py:159-160);
+GPU tensors run the gfx950 library or raise -- there is no fallback between the two.  fp64 inputs run
+a double-arithmetic kernel (the reference dispatches double too, upfirdn2d_kernel.cu:311).
+Differentiable: the gradient is
 another upfirdn2d with the flipped kernel and swapped factors (op/upfirdn2d.py:20-61,
 108-117), executed by the same HIP kernel.
 """
@@ -13,7 +15,9 @@ from collections import abc
 import torch
 from torch.autograd import Function
 
+from .. import _lib
 from .. import kernels as K
+from . import native
 
 
 def _planes(x, fir, up, down, pad):
@@ -56,7 +60,10 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     up, down, pad = tuple(int(v) for v in up), tuple(int(v) for v in down), tuple(int(v) for v in pad)
     if input.ndim != 4:
         raise ValueError("upfirdn2d expects an (N, C, H, W) tensor")
-    fir = kernel.detach().to(device=input.device, dtype=torch.float32).contiguous()
-    if fir.ndim != 2:
+    if kernel.ndim != 2:
         raise ValueError("upfirdn2d expects a 2-D FIR kernel")
+    if input.device.type == "cpu" and not _lib.emulation_injected():   # (the emulation: tests running the kernel sources on the host)
+        return native.upfirdn2d(input, kernel.detach(), up, down, pad)
+    fir = kernel.detach().to(device=input.device,
+                             dtype=torch.float64 if input.dtype == torch.float64 else torch.float32).contiguous()
     return _UpFirDn2d.apply(input, fir, up, down, pad)

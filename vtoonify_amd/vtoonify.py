@@ -4,7 +4,10 @@
 The module tree below only HOLDS parameters under the reference's names (399 state_dict
 entries for backbone='dualstylegan', 229 for 'toonify') so that
 `VToonify(backbone).load_state_dict(ckpt['g_ema'])` (style_transfer.py:62-64) works
-unchanged.  All arithmetic happens in the HIP engine; there is no eager fallback.
+unchanged.  With the parameters on a GPU all arithmetic happens in the HIP engine and nothing
+falls back; with the parameters on the CPU (`style_transfer.py --cpu`, :32,55) the forward
+pass is the reference's eager operator sequence over the CPU-tensor branch of the operator
+surface (eager.py, op/native.py) -- the reference's own "CPU tensors -> native path" contract.
 Initial values follow the reference initialisers (randn for StyleGAN2 weights, default
 nn.Conv2d/nn.Linear init, identity-like T_s, x0.01 ModRes filters) but are not
 bit-identical to it -- real use loads a checkpoint.
@@ -18,6 +21,8 @@ from typing import Optional
 import torch
 from torch import nn
 
+from . import _lib
+from .eager import EagerVToonify
 from .engine import VToonifyEngine
 from .synth import fir_kernel_2d
 
@@ -310,10 +315,21 @@ class VToonify(nn.Module):
         On a GPU the frame is one hipGraph replay (captured on the first call of a shape; one plan per
         calling stream), i.e. the path bench.py measures; whether the B style rows are identical is
         decided without a host sync for expand()ed / single-row styles and once per style tensor otherwise."""
+        if self._on_cpu():
+            with torch.no_grad():
+                return EagerVToonify(self.state_dict(), self.backbone, self.in_size).forward(
+                    x, style, d_s, return_mask=return_mask, return_feat=return_feat)
         return self.engine().forward(x, style, d_s, return_mask=return_mask, return_feat=return_feat)
+
+    def _on_cpu(self) -> bool:
+        """Parameters on the CPU and no test emulation bound: the reference's CPU path (`--cpu`)."""
+        return next(self.parameters()).device.type == "cpu" and not _lib.emulation_injected()
 
     def stylegan(self):
         return self.generator.generator if self.backbone == "dualstylegan" else self.generator
 
     def zplus2wplus(self, zplus):
+        if self._on_cpu():
+            with torch.no_grad():
+                return EagerVToonify(self.state_dict(), self.backbone, self.in_size).zplus2wplus(zplus)
         return self.engine().map_style(zplus)
