@@ -155,7 +155,11 @@ def test_reference_eager_graph_on_the_gpu_library_256_vs_oracle():
     dev = torch.device("cuda:0")
     sd = synth.synth_state_dict(load_keys("D"), 0)
     x, s = synth.synth_frames(1, 256, 256, seed=11), synth.synth_style(seed=12)
-    ref = O.vtoonify_forward(synth.to_numpy_sd(sd), x.numpy(), s.numpy(), 0.5, "dualstylegan")
+    old = O.set_backend("torch")   # full size: minutes with the numpy contractions, seconds with F.conv2d
+    try:
+        ref = O.vtoonify_forward(synth.to_numpy_sd(sd), x.numpy(), s.numpy(), 0.5, "dualstylegan")
+    finally:
+        O.set_backend(old)
     sd_dev = {k: v.to(dev) for k, v in sd.items()}
     with torch.no_grad():
         y = EagerVToonify(sd_dev, "dualstylegan", 256).forward(x.to(dev), s.to(dev), 0.5)

@@ -662,6 +662,96 @@ def test_conv_patch_pipelined_equals_per_tap(dev, dtype, monkeypatch):
         assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < (F32_TOL if dtype == torch.float32 else 8e-3)
 
 
+def test_conv_patch_chunk_equals_pipelined(dev, monkeypatch):
+    """conv_patchc_kernel (csrc/conv_patch_chunk.hpp, round 6): the 32-channel tiles with all nine taps of a chunk resident and ONE
+    barrier per chunk.  Same tile, same loader addresses, same K order as the tap-granular pipeline (VT_PATCH_PIPE=1 ->
+    conv_patchp_kernel<T,16,32,8,1,8>): the SAME BITS -- one chunk, many chunks (both chunk buffers in use), two concatenated
+    sources whose seam is a chunk boundary, ragged tile edges, a batch, more channel tiles than one, split-K slices (uneven), the
+    lean epilogue (no residual) and the general one."""
+    dtype = torch.bfloat16
+    g = np.random.default_rng(61)
+    # dil = 2 (conv_patchc_kernel<.., DIL = 2>: tiles over the four sub-images of an image, dense 18 x 18 patches of a sub-image)
+    # against conv_patchp_kernel<.., DIL = 2> (20 x 20 patches of the full image): even and odd sizes, sub-images smaller and
+    # larger than a tile
+    for N, c0, c1, H, W, cout, split, resid, dil in ((1, 64, 0, 16, 16, 32, 0, False, 1), (2, 320, 0, 21, 35, 72, 0, True, 1),
+                                                      (1, 64, 128, 33, 17, 40, 0, True, 1), (3, 256, 0, 32, 32, 64, 0, False, 1),
+                                                      (1, 448, 0, 19, 18, 96, 3000000, True, 1),
+                                                      (4, 512, 0, 32, 32, 64, 0, True, 1),
+                                                      (4, 256, 0, 32, 32, 64, 0, True, 2), (2, 128, 0, 21, 35, 40, 0, False, 2),
+                                                      (1, 64, 64, 45, 50, 32, 0, True, 2), (1, 192, 0, 18, 32, 72, 2000000, True, 2)):
+        cin = c0 + c1
+        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
+        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        xa = K.nchw_to_nhwc(T(x[:, :c0], dev), dtype)
+        xb = K.nchw_to_nhwc(T(x[:, c0:], dev), dtype) if c1 else None
+        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
+        ldo = (cout + 7) // 8 * 8
+        r = K.nchw_to_nhwc(T(g.standard_normal((N, cout, H, W)).astype(np.float32), dev), dtype, ld_out=ldo) if resid else None
+        ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+
+        def run():
+            out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
+            kw = dict(src1=xb, c1=c1, ld1=c1) if c1 else {}
+            if resid:
+                kw.update(alpha=0.5, beta=0.25, resid=r, ld_res=ldo)
+            K.conv2d(src0=xa, c0=c0, ld0=c0, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=dil, dil=dil,
+                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=ldo, dtype=K.dt_code(dtype),
+                     tile_hint=P + split + 256032, splitk_ws=ws, **kw)
+            return out
+        monkeypatch.setenv("VT_PATCH_PIPE", "1")
+        ref = run()
+        monkeypatch.delenv("VT_PATCH_PIPE")
+        got = run()
+        assert torch.equal(got, ref), (N, c0, c1, H, W, cout, split, dil)
+        xq = torch.cat([xa] + ([xb] if c1 else []), dim=3).float().cpu().permute(0, 3, 1, 2).numpy()
+        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        want = O.leaky_relu(O.conv2d(xq, wq, b, 1, dil, dil), 0.2) * np.float32(2 ** 0.5)
+        if resid:
+            want = want * 0.5 + 0.25 * r.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy()
+        assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < 8e-3
+
+
+def test_conv_stride2_by_input_parity(dev):
+    """conv_patchs2_kernel (csrc/conv_patch_s2.hpp, round 6): the encoder's stride-2 3x3 convs (model/vtoonify.py:167-176) as four
+    dense convs on the parity sub-images of the input, patch-resident.  Against the oracle: one and several chunks, ragged tiles
+    in both directions (output sizes that are not multiples of 16), a ragged channel tile, a batch, LeakyReLU with and without a
+    residual (general / lean epilogue), planar fp32 output; the frame of a batch equals the frame alone (no K split, the kernel
+    choice is per image from 128 tiles up); and the plan query picks it for the 256^2 and 128^2 stages of the encoder, for the
+    64^2 one only in a batch."""
+    import ctypes
+    from vtoonify_amd import _lib
+    S2 = 700000000 + 256064
+    dt, L = torch.bfloat16, K.ACT_LRELU
+    for N, cin, H, W, cout, resid, planar in ((1, 64, 32, 32, 64, False, False), (2, 128, 40, 72, 64, True, False),
+                                              (1, 192, 36, 20, 72, False, False), (3, 64, 16, 16, 40, True, False),
+                                              (1, 128, 66, 34, 128, False, True)):
+        assert _conv_case(dev, dt, N, cin, H, W, cout, 3, 2, 1, 1, act=L, resid=resid, planar=planar, hint=S2) < 8e-3, \
+            (N, cin, H, W, cout)
+    x = torch.zeros((1,), dtype=dt, device=dev)
+    for cin, cout, hw, want1, want4 in ((128, 256, 256, 7, 7), (256, 512, 128, 7, 7), (512, 512, 64, 2, 7)):
+        for n, want in ((1, want1), (4, want4)):   # (the deepest stage: 32 tiles per image -- the 1-D tiles alone, this kernel in a batch)
+            d = K.make_conv_desc(src0=x, c0=cin, ld0=cin, n=n, h=hw, w=hw, out_h=hw // 2, out_w=hw // 2, weight=x, cout=cout, kh=3,
+                                 kw=3, stride=2, pad=1, out=x, ld_out=cout, dtype=K.VT_BF16)
+            d.splitk_ws, d.splitk_ws_bytes = x.data_ptr(), 1 << 40
+            assert _lib.lib().vt_conv2d_tile(ctypes.byref(d)) // 100000000 == want, (cin, cout, hw, n)
+    # a frame inside a batch == the frame alone
+    g = np.random.default_rng(7)
+    xs = g.standard_normal((3, 128, 32, 48)).astype(np.float32)
+    w = (g.standard_normal((64, 128, 3, 3)) / 34.0).astype(np.float32)
+    wp = K.pack_conv_weight(T(w, dev), out_dtype=dt)
+
+    def run(xn):
+        xt = K.nchw_to_nhwc(T(xn, dev), dt)
+        out = torch.zeros((xn.shape[0], 16, 24, 64), dtype=dt, device=dev)
+        K.conv2d(src0=xt, c0=128, ld0=128, n=xn.shape[0], h=32, w=48, out_h=16, out_w=24, weight=wp, cout=64, kh=3, kw=3, stride=2,
+                 pad=1, out=out, ld_out=64, dtype=K.VT_BF16, tile_hint=S2)
+        return out
+    full = run(xs)
+    for i in range(3):
+        assert torch.equal(run(xs[i:i + 1])[0], full[i])
+
+
 def test_conv_patch_persistent_equals_one_workgroup_per_tile(dev, monkeypatch):
     """conv_patchq_kernel (csrc/conv_patch_persist.hpp): persistent workgroups walk contiguous ranges of tiles and the loader
     prefetches across tile boundaries (the successor's first patch and taps land during the epilogue).  Same K order, same lean

@@ -54,12 +54,27 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stamp(hipcc: str, flags) -> str:
+    """What the objects were built WITH: the flags and the compiler.  A change of FLAGS alone (-fno-slp-vectorize is the fix
+    for a wrong-result defect) must not leave objects of the old flags linked into the product."""
+    import hashlib
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = ""
+    return hashlib.sha256((" ".join(flags) + "\n" + ver).encode()).hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
     flags = list(FLAGS)
+    stamp_file = os.path.join(objdir, "flags.stamp")
+    stamp = _stamp(hipcc, flags)
+    if not (os.path.exists(stamp_file) and open(stamp_file).read() == stamp):
+        force = True    # other flags or another compiler: every object is stale
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -76,6 +91,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     out = lib_path()
     if force or jobs or _stale(out, objs):

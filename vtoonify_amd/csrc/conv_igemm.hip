@@ -848,10 +848,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x4 (&acc)[BM
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[4 * h + i] = conv_finish(p, acc[a][b0 + h][i], bv[h][i], ga, sv[h][i]);
                 if (rgbf && nh[h] < p.coutT) {
+                    // the ToRGB conv reads the activation as it is STORED (rounded to T): the un-fused launch does, and so do the
+                    // MFMA forms of the lean / c32 / resident epilogues -- every fused form multiplies the same operands
+                    float fr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fr[i] = to_f32(from_f32<T>(f[4 * h + i]));
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
-                        rp[a][j] += (f[4 * h] * wr[h][j][0] + f[4 * h + 1] * wr[h][j][1]) +
-                                    (f[4 * h + 2] * wr[h][j][2] + f[4 * h + 3] * wr[h][j][3]);
+                        rp[a][j] += (fr[0] * wr[h][j][0] + fr[1] * wr[h][j][1]) + (fr[2] * wr[h][j][2] + fr[3] * wr[h][j][3]);
                 }
             }
             if (BS == 2 && nh[1] < p.coutT && store_out8_bf16(p, m, nh[0], f, rvec, rpre[b0 / BS][a])) continue;
@@ -1158,7 +1162,12 @@ conv_igemm_glds_kernel(const ConvArgs p, const GldsArgs g) {
     const int wave = vt_uniform(tid >> 6) & 3;
     const int wm = wave / WN, wn = wave % WN;
     int tile_m, tile_n, split;
-    decode_block(p, tile_m, tile_n, split);
+    if (p.blk_pm < 0) {   // pixel-major order (launch_cfg): the channel tiles of one pixel tile run together on one XCD
+        decode_block_pixel_major(p, tile_m, tile_n);
+        split = 0;
+    } else {
+        decode_block(p, tile_m, tile_n, split);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HoWo = p.Ho * p.Wo;
 
@@ -1714,6 +1723,8 @@ static int device_cus();
 #include "conv_upblur_rows.hpp"
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
+#include "conv_patch_chunk.hpp"
+#include "conv_patch_s2.hpp"
 #include "conv_patch_resident.hpp"
 #include "conv_patch_persist.hpp"
 
@@ -2016,6 +2027,14 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
     if (args.phase == 2) {
         // reduce pass only (the slices were launched by an earlier vt_conv2d with phase 1)
     } else if (glds_eligible<T>(args, g)) {
+        // Which operand every XCD re-reads.  decode_block's order is channel-major: XCD x owns a range of channel tiles and
+        // ALL pixels, so the input crosses the fabric once per XCD -- 331 MB per launch for the stride-2 encoder convs against
+        // 39 MB of operands (profiles/r05_pmc_traffic.json).  Pixel-major (an XCD owns a range of pixel tiles and every channel
+        // tile of them) makes the WEIGHTS the re-read operand instead: chosen when they are the smaller one.  No K split only
+        // (the slices of a tile are consecutive in decode_block's order).  Which workgroup computes a tile never changes its bits.
+        if (args.splitk == 1 && args.tiles_n > 1 &&
+            (int64_t)a.N * a.H * a.W * a.cin > (int64_t)a.coutT * a.K)
+            args.blk_pm = -1;
         // As many LDS stages (K-steps of loads in flight) as still let TWO workgroups share a
         // CU's 160 KiB: measured on MI355X, occupancy 2 with 2 stages beats occupancy 1 with 3
         // (128x128: 2 stages; 128x64 / 64x128: 3; 64x64 and smaller: 4)
@@ -2054,7 +2073,8 @@ int launch_cfg(const ConvArgs& a, vt_stream stream) {
 // ---------------------------------------------------------------------------------------
 struct TilePlan {
     int kind;  // 0 = 1-D tile GEMM kernels, 1 = patch-resident 3x3 kernel, 3 = persistent 32->32, 4 = whole-K (conv_fullk.hpp),
-               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp), 7 = persistent 64->64,
+               // 5 = conv_transpose + blur (conv_upblur.hpp), 6 = thin outputs (conv_thin.hpp), 7 = stride-2 3x3 by input parity
+               // (conv_patch_s2.hpp; rounds 2-3: the retired persistent 64->64 kernel),
                // 8 = whole-K, weight-stationary over G tiles (conv_fullkw.hpp; bm = 64 * G)
     int bm, bn, splitk;
 };
@@ -2190,6 +2210,21 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         return (int64_t)vt_cdiv(a.Ho, th) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, n);
     };
     GldsArgs g;
+    if constexpr (sizeof(T) == 2) {
+        // stride-2 3x3 convs (the encoder's down-sampling convs) by input parity on patch-resident tiles (conv_patch_s2.hpp):
+        // from 128 tiles up -- per IMAGE under VT_BATCH_EXACT (its K order is not the 1-D kernel's, so the choice must then not
+        // look at the batch), per launch otherwise (like the other batch-aware plans, section 4.1h of DESIGN.md): the 64^2 ->
+        // 32^2 conv of the deepest stage has 32 tiles per image and takes this kernel from 4 frames up, the 1-D tiles with a
+        // K split below
+        GldsArgs gs;
+        if ((hp == 7 || (hp == 0 && hbm == 0 && hs == 0 && (batch_exact() ? 1 : a.N) * ptiles(16, 64) >= 128)) &&
+            patchs2_eligible<T>(a, gs)) {
+            t.kind = 7;
+            t.bm = 256, t.bn = 64;
+            t.splitk = 1;
+            return t;
+        }
+    }
     if (hp != 2 && hbm == 0 && c32_eligible<T>(a, g)) {   // the 1024^2 level: persistent register-weight kernel
         t.kind = 3;
         t.bm = 256;
@@ -2478,6 +2513,41 @@ int launch_patchp(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
+// one barrier per K chunk (conv_patch_chunk.hpp): the 32-channel tiles of the trunk.  Same tiles, same split rules, same bits as
+// launch_patchp<T, 16, 32, 8, 1, ...>
+template <typename T, int DIL = 1>
+int launch_patchc(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
+    constexpr int TH = 16, BN = 32, WM = 8, WN = 1;
+    constexpr int BK = 8 * (16 / (int)sizeof(T));
+    ConvArgs args = a;
+    args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;
+    args.tiles_n = vt_cdiv(a.coutT, BN);
+    // (DIL > 1: tiles over the DIL x DIL sub-images of every image, conv_patch_chunk.hpp)
+    args.tiles_m = a.N * DIL * DIL * vt_cdiv(vt_cdiv(a.Ho, DIL), TH) * vt_cdiv(vt_cdiv(a.Wo, DIL), 16);
+    const int units = a.cin / BK;
+    args.kps = vt_cdiv(units, args.splitk);
+    args.splitk = vt_cdiv(units, args.kps);
+    split_mode(args);
+    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n * args.splitk;
+    if (blocks >= ((int64_t)1 << 31)) {
+        vt_set_error("vt_conv2d: too many tiles");
+        return VT_ERR_ARG;
+    }
+    xcd_block(args, blocks, (int64_t)(TH + 2) * (16 + 2) * a.cin * (int)sizeof(T), (int64_t)BN * a.K * (int)sizeof(T));
+    if (args.phase != 2) {
+        if (args.splitk == 1 && conv_lean<T>(args)) {
+            auto k = conv_patchc_kernel<T, TH, BN, WM, WN, 1, DIL>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        } else {
+            auto k = conv_patchc_kernel<T, TH, BN, WM, WN, 0, DIL>;
+            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(WM * WN * 64), stream, args, g);
+        }
+    }
+    int rc = vt_check_launch("vt_conv2d(patch, chunk barriers)");
+    if (rc != VT_OK || args.splitk == 1 || args.tickets || args.phase == 1) return rc;
+    return launch_reduce<T>(args, stream);
+}
+
 // weights-resident persistent form (conv_patch_resident.hpp): one chunk of K, one channel tile, no split
 template <typename T, int TH, int BN>
 int launch_patchw(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
@@ -2600,6 +2670,14 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
         return VT_ERR_UNSUPPORTED;
     }
     if (t.kind == 6) return launch_thin<T>(a, stream);
+    if (t.kind == 7) {
+        GldsArgs gs;
+        if constexpr (sizeof(T) == 2) {
+            if (patchs2_eligible<T>(a, gs)) return launch_patchs2<T>(a, gs, stream);
+        }
+        vt_set_error("vt_conv2d: stride-2 patch kernel requested for an ineligible convolution");
+        return VT_ERR_UNSUPPORTED;
+    }
     if (t.kind == 8) {
         FullkwArgs wg;
         if (!fullkw_eligible<T>(a, a.wstream, wg)) {
@@ -2670,7 +2748,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // (VT_PATCH_PIPE=1: one workgroup per tile, A/B).  VT_BATCH_EXACT or not: the same bits either way.
             if constexpr (sizeof(T) == 2) {
                 if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && (t.bn == 128 || t.bn == 64) && a.splitk <= 1 &&
-                    conv_lean<T>(a) && vt_cdiv(a.coutT, t.bn) * t.bn * 8 <= 6144 &&   // (the tables of every channel tile: 6 KB of LDS)
+                    conv_lean<T>(a) && vt_cdiv(a.coutT, t.bn) * t.bn * 8 <= PQ_TAB_BYTES &&   // (the tables of every channel tile, conv_patch_persist.hpp)
                     (int64_t)a.N * vt_cdiv(a.Ho, 16) * vt_cdiv(a.Wo, 16) * vt_cdiv(a.coutT, t.bn) > patchw_wgs()) {
                     if (t.bn == 128) return launch_patchq<T, 16, 128, 4, 2, 4>(a, g, stream);
                     return launch_patchq<T, 16, 64, 4, 2, 4>(a, g, stream);
@@ -2678,6 +2756,13 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 128) return launch_patchp<T, 16, 128, 4, 2>(a, g, stream);
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 64) return launch_patchp<T, 16, 64, 4, 2, 4>(a, g, stream);
+            // 32-channel tiles: all nine taps of a chunk resident, one barrier per chunk (conv_patch_chunk.hpp; VT_PATCH_PIPE=1:
+            // the tap-granular pipeline, A/B -- same bits)
+            if constexpr (sizeof(T) == 2) {
+                if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchc<T>(a, g, stream);
+                if (pipe && !(e && e[0] == '1') && a.dil == 2 && t.bm == 256 && t.bn == 32 && !a.stats_part)
+                    return launch_patchc<T, 2>(a, g, stream);
+            }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
             if (pipe && a.dil == 2 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 6, 0, 2>(a, g, stream);
         }

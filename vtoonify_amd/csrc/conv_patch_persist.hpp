@@ -15,6 +15,11 @@
 // ToRGB exchange (the operand buffers are never idle here).
 #pragma once
 
+// LDS bytes the persistent kernel keeps for the epilogue tables of EVERY channel tile (bias / slope / gain: 8 bytes per channel),
+// behind the patch: ONE constant for the kernel's static_assert and for the host's admission test in dispatch() (the
+// two used to be 4096 and 6144 and agreed only for TH = 16, NW = 8)
+constexpr int PQ_TAB_BYTES = 6144;
+
 template <typename T, int TH, int BN, int WM, int WN, int NSTB = 4>
 __global__ void __launch_bounds__(WM * WN * 64)
 conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
@@ -41,7 +46,7 @@ conv_patchq_kernel(const ConvArgs p, const GldsArgs g) {
     static_assert(2 * A_BYTES + NSTB * B_BYTES <= 160 * 1024, "LDS budget");
     static_assert((D - 2) * LB + PA < 64, "vmcnt is 6 bits");
     static_assert(WN == 1 || X_OFF + BM * WN * 12 <= A_BYTES, "room for the ToRGB exchange behind the patch");
-    static_assert(A_BYTES - X_OFF >= 4096, "room for the epilogue tables of every channel tile (host: tiles_n * BN * 8 bytes)");
+    static_assert(A_BYTES - X_OFF >= PQ_TAB_BYTES, "room for the epilogue tables of every channel tile (the host admits tiles_n * BN * 8 <= PQ_TAB_BYTES)");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES + NSTB * B_BYTES];
 

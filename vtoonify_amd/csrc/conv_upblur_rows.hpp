@@ -378,7 +378,9 @@ static bool uprows_wanted(const ConvArgs& a) {
         if (e && e[0] == '0') return false;
         if (a.cin != 64 && a.cin != 128) return false;
         if (a.ld0 % 8 != 0 || (uintptr_t)a.src0 % 16 != 0 || a.ld_out % 8 != 0 || (uintptr_t)a.out % 16 != 0) return false;
-        if ((int64_t)a.N * 4 * a.H * a.W * a.ld_out * 2 >= ((int64_t)1 << 31) - 4096) return false;   // range-checked stores
+        // range-checked 32-bit stores: ONE image must fit the window; a batch that does not is cut into groups of images by
+        // launch_uprows (the choice of kernel -- hence the bits of a frame -- must not depend on the batch)
+        if ((int64_t)4 * a.H * a.W * a.ld_out * 2 >= ((int64_t)1 << 31) - 4096) return false;
         return (e && e[0] == '1') || (int64_t)a.H * a.W >= 128 * 128;
     }
 }
@@ -387,6 +389,25 @@ template <typename T>
 int launch_uprows(const ConvArgs& a, vt_stream stream) {
     UpblurArgs ub;
     UprowsArgs g;
+    {   // batches beyond the 32-bit range of the counted loads / stores: groups of images, each its own launch on offset
+        // pointers (only src0 and out are per image).  A frame's bits do not depend on the group it rides in.
+        const int64_t lim = ((int64_t)1 << 31) - 4096;
+        const int64_t in_img = (int64_t)a.H * a.W * a.ld0 * 2, out_img = (int64_t)4 * a.H * a.W * a.ld_out * 2;
+        const int64_t per = in_img > out_img ? in_img : out_img;
+        if (per > 0 && (int64_t)a.N * per >= lim && a.N > 1) {
+            const int gn = (int)((lim - 1) / per) > 0 ? (int)((lim - 1) / per) : 1;
+            for (int n0 = 0; n0 < a.N; n0 += gn) {
+                ConvArgs sub = a;
+                sub.N = a.N - n0 < gn ? a.N - n0 : gn;
+                sub.src0 = (const char*)a.src0 + (int64_t)n0 * in_img;
+                sub.out = (char*)a.out + (int64_t)n0 * out_img;
+                sub.M = sub.N * a.Ho * a.Wo;
+                const int rc = launch_uprows<T>(sub, stream);
+                if (rc != VT_OK) return rc;
+            }
+            return VT_OK;
+        }
+    }
     if (!upblur_eligible<T>(a, ub, 2, UR_OW)) {
         vt_set_error("vt_conv2d: up_fir (conv_transpose + blur) form not supported for this convolution");
         return VT_ERR_UNSUPPORTED;

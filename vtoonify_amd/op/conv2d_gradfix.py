@@ -100,7 +100,9 @@ def _launch(input, weight, bias, stride, padding, dilation, groups, transposed, 
     # wide outputs: NHWC out of the fast epilogues + one tiled layout change (vt_nhwc_to_nchw); narrow ones (ToRGB, masks)
     # keep the planar output of the thin kernels
     via_nhwc = cout_g >= 32 and cout_g % 8 == 0
-    out = torch.empty((n, cout, out_h, out_w), dtype=(dtype if via_nhwc else torch.float32), device=input.device)
+    # (the NHWC path of an ungrouped conv returns its own tensor: nothing is allocated here for it -- ADVICE r5)
+    out = None if (via_nhwc and groups == 1) else \
+        torch.empty((n, cout, out_h, out_w), dtype=(dtype if via_nhwc else torch.float32), device=input.device)
     for g in range(groups):
         xg = x[:, g * cin_g:(g + 1) * cin_g].contiguous() if groups > 1 else x
         x_nhwc = K.nchw_to_nhwc(xg, dtype, ld_out=cpad)
@@ -141,7 +143,10 @@ def _output_padding(cfg, input_shape, output_shape, weight_shape):
                  - dilation * (weight_shape[i + 2] - 1) for i in range(2))
 
 
-_GW_CHUNK_BYTES = 1 << 30   # one im2col operand per GEMM launch stays below this (32-bit buffer ranges of the kernels)
+_GW_CHUNK_BYTES = 1 << 28   # one im2col operand per GEMM launch stays below this (transient memory of a backward conv: the A
+#                             operand, the fp32 copy of grad_output the weight packer reads and its packed form -- ADVICE r5: 1 GiB
+#                             chunks put 2-4 GB of transients on a 128-channel 256^2 layer; the 32-bit buffer ranges of the kernels
+#                             allow far more)
 
 
 def _grad_weight_kernel(inp, grad, kh, kw, stride, padding, dilation):
@@ -167,7 +172,7 @@ def _grad_weight_kernel(inp, grad, kh, kw, stride, padding, dilation):
     xp = torch.nn.functional.pad(inp.detach(), (p, p, p, p)).transpose(0, 1)     # (Ca, N, Hp, Wp) view
     gt = grad.detach().transpose(0, 1)                                            # (Cb, N, Ho, Wo) view
     # groups of (images, output rows) whose operands fit the chunk size
-    per_row = max(m, cb) * wo * esz
+    per_row = max(m * esz, cb * (4 + esz)) * wo          # A rows, or grad_output's fp32 copy + its packed form
     if per_row * ho <= _GW_CHUNK_BYTES:
         step = max(1, _GW_CHUNK_BYTES // (per_row * ho))
         groups = [(i, min(n, i + step), 0, ho) for i in range(0, n, step)]
