@@ -84,6 +84,33 @@ def test_upfirdn2d_wide_plane_kernel(dev, dtype):
             assert rel_err(y.float().cpu().numpy(), ref) < 8e-3, (shape, pad)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_upfirdn2d_wide_plane_kernel_16bit_phases(dev, dtype):
+    """The wide tile on 16-bit tensors at every 2-byte phase (written in round 6 for a loader that kept the window raw in LDS --
+    measured slower and dropped, profiles/r06_upfirdn2d_experiments.txt; the cases stay as a regression for any loader): plane
+    widths of all residues mod 8 (consecutive rows walk through all phases), tensors that do not start on a 16-byte boundary
+    (views at element offsets 1..7), first and last plane with a foreign neighbour on both sides, left / right / top / bottom
+    edge tiles with pads and crops, a 1 x 4 and a 4 x 1 FIR.  Integer data, dyadic taps: the result is the exact sum rounded
+    ONCE to the 16-bit type."""
+    g = np.random.default_rng(16)
+    k4 = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 16.0).astype(np.float32)
+    row = (np.array([[1.0, 3, 3, 1]]) / 4.0).astype(np.float32)
+    for w in (513, 514, 515, 516, 517, 518, 519, 520):
+        for off, k, pad in ((w % 8, k4, (1, 1)), ((w + 3) % 8, row, (2, 1, 0, 0)), (0, row.T.copy(), (0, 0, 1, 2)), (5, k4, (-2, 3, 1, -1))):
+            shape = (2, 2, 18, w)
+            x = g.integers(-8, 9, shape).astype(np.float32)
+            n = int(np.prod(shape))
+            buf = torch.full((n + 16,), 77.0, dtype=dtype, device=dev)      # a neighbour that must never leak into the result
+            xt = buf[off:off + n].view(shape)
+            xt.copy_(T(x, dev, dtype))
+            y = op.upfirdn2d(xt, T(k, dev), pad=pad)
+            ref = O.upfirdn2d(x, k, 1, 1, pad)
+            assert y.shape == ref.shape and y.dtype == dtype
+            # small integers, dyadic taps: the fp32 sums are exact, so the result is `ref` rounded ONCE to the 16-bit type
+            want = torch.from_numpy(ref).to(dtype).float().numpy()
+            assert np.array_equal(y.float().cpu().numpy(), want), (w, off, pad)
+
+
 def test_upfirdn2d_properties(dev):
     """Size-independent checks at a realistic size: linearity and the identity kernel."""
     g = torch.Generator().manual_seed(3)
@@ -726,8 +753,9 @@ def test_conv_stride2_by_input_parity(dev):
     for N, cin, H, W, cout, resid, planar in ((1, 64, 32, 32, 64, False, False), (2, 128, 40, 72, 64, True, False),
                                               (1, 192, 36, 20, 72, False, False), (3, 64, 16, 16, 40, True, False),
                                               (1, 128, 66, 34, 128, False, True)):
-        assert _conv_case(dev, dt, N, cin, H, W, cout, 3, 2, 1, 1, act=L, resid=resid, planar=planar, hint=S2) < 8e-3, \
-            (N, cin, H, W, cout)
+        for hint in (S2, S2 - 32):   # 64- and 32-channel tiles
+            assert _conv_case(dev, dt, N, cin, H, W, cout, 3, 2, 1, 1, act=L, resid=resid, planar=planar, hint=hint) < 8e-3, \
+                (N, cin, H, W, cout, hint)
     x = torch.zeros((1,), dtype=dt, device=dev)
     for cin, cout, hw, want1, want4 in ((128, 256, 256, 7, 7), (256, 512, 128, 7, 7), (512, 512, 64, 2, 7)):
         for n, want in ((1, want1), (4, want4)):   # (the deepest stage: 32 tiles per image -- the 1-D tiles alone, this kernel in a batch)
@@ -750,6 +778,12 @@ def test_conv_stride2_by_input_parity(dev):
     full = run(xs)
     for i in range(3):
         assert torch.equal(run(xs[i:i + 1])[0], full[i])
+    # ... and the 32-channel tiles give the bits of the 64-channel ones (same K order): the width may follow the batch
+    xt = K.nchw_to_nhwc(T(xs, dev), dt)
+    o32 = torch.zeros((3, 16, 24, 64), dtype=dt, device=dev)
+    K.conv2d(src0=xt, c0=128, ld0=128, n=3, h=32, w=48, out_h=16, out_w=24, weight=wp, cout=64, kh=3, kw=3, stride=2, pad=1, out=o32,
+             ld_out=64, dtype=K.VT_BF16, tile_hint=S2 - 32)
+    assert torch.equal(o32, full)
 
 
 def test_conv_patch_persistent_equals_one_workgroup_per_tile(dev, monkeypatch):

@@ -2220,7 +2220,8 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         if ((hp == 7 || (hp == 0 && hbm == 0 && hs == 0 && (batch_exact() ? 1 : a.N) * ptiles(16, 64) >= 128)) &&
             patchs2_eligible<T>(a, gs)) {
             t.kind = 7;
-            t.bm = 256, t.bn = 64;
+            // 32-channel tiles where 64-channel ones leave CUs idle (same K order: the same bits at both widths)
+            t.bm = 256, t.bn = (hbn == 32 || (hbn != 64 && (batch_exact() ? 1 : a.N) * ptiles(16, 64) < 256)) ? 32 : 64;
             t.splitk = 1;
             return t;
         }
@@ -2673,7 +2674,7 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
     if (t.kind == 7) {
         GldsArgs gs;
         if constexpr (sizeof(T) == 2) {
-            if (patchs2_eligible<T>(a, gs)) return launch_patchs2<T>(a, gs, stream);
+            if (patchs2_eligible<T>(a, gs)) return t.bn == 32 ? launch_patchs2<T, 32>(a, gs, stream) : launch_patchs2<T, 64>(a, gs, stream);
         }
         vt_set_error("vt_conv2d: stride-2 patch kernel requested for an ineligible convolution");
         return VT_ERR_UNSUPPORTED;

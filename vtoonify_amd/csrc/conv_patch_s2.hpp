@@ -39,7 +39,7 @@ conv_patchs2_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int A_BYTES = NPA * 1024, B_BYTES = NPB * 1024;
     constexpr int S_BYTES = A_BYTES + 4 * B_BYTES;              // one step: sub-patch + up to four slabs
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0 && TM * WM == TH, "wave tiling");
-    static_assert(NPB == NW, "round i of the weight loads is tap i of the class: one piece per wave");
+    static_assert(NW % NPB == 0, "a wave's weight pieces are the same rows of every slab it loads");
     static_assert(2 * S_BYTES <= 160 * 1024, "LDS budget: two steps");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * S_BYTES];
@@ -73,7 +73,7 @@ conv_patchs2_kernel(const ConvArgs p, const GldsArgs g) {
     }
     uint32_t woff;
     {
-        const int row = wave * 8 + lrow;               // (NPB == NW: this wave's 8 rows of every slab)
+        const int row = (wave % NPB) * 8 + lrow;       // weight piece w = i * NW + wave of a class: slab w / NPB, rows (w % NPB) * 8 ..
         const int n = n0 + tile_row_channel<PERM>(row);
         woff = (n < p.coutT) ? (uint32_t)n * (uint32_t)(p.K * ESZ) + jj * 16 : GLDS_OOB;
     }
@@ -92,10 +92,14 @@ conv_patchs2_kernel(const ConvArgs p, const GldsArgs g) {
         for (int i = 0; i < PA; ++i)
             if ((i + 1) * NW <= NPA || i * NW + wave < NPA)
                 vt_glds16(r0, smem + soff + (i * NW + wave) * 1024, pa0[i], so);
+        constexpr int LBR = (NT * NPB + NW - 1) / NW;   // weight rounds of the class
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int i = 0; i < LBR; ++i) {
+            const int w = i * NW + wave;                // piece of the class's NT * NPB
+            const int j = w / NPB;                      // its tap (wave-uniform)
             const int ky = PR ? (j / (PC ? 2 : 1)) * 2 : 1, kx = PC ? (j % 2) * 2 : 1;
-            vt_glds16(rw, smem + soff + A_BYTES + j * B_BYTES + wave * 1024, woff, (uint32_t)(((ky * 3 + kx) * p.cin + chunk * BK) * ESZ));
+            if ((i + 1) * NW <= NT * NPB || w < NT * NPB)
+                vt_glds16(rw, smem + soff + A_BYTES + w * 1024, woff, (uint32_t)(((ky * 3 + kx) * p.cin + chunk * BK) * ESZ));
         }
     };
 
@@ -199,9 +203,11 @@ static bool patchs2_eligible(const ConvArgs& a, GldsArgs& g) {
     return true;
 }
 
-template <typename T>
+// BN = 64: 8 waves of 64 pixels x 32 channels.  BN = 32 (8 waves of 32 x 32): twice the workgroups -- the deepest stage (64^2 ->
+// 32^2, 16 pixel tiles at 4 frames) fills the GPU with it; its patches are read twice as often.
+template <typename T, int BN = 64>
 int launch_patchs2(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
-    constexpr int TH = 16, BN = 64, WM = 4, WN = 2;
+    constexpr int TH = 16, WM = BN == 64 ? 4 : 8, WN = BN == 64 ? 2 : 1;
     ConvArgs args = a;
     args.slab_perm = ((BN / WN / 16) % 2 == 0) ? 1 : 0;
     args.tiles_n = vt_cdiv(a.coutT, BN);

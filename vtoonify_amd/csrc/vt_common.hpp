@@ -94,7 +94,15 @@ __device__ __forceinline__ float from_f32<float>(float f) {
 template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
     bf16_t r;
+#ifdef VT_EMU
     r.v = (uint16_t)f32_to_bf16_bits(f);
+#else
+    // v_cvt_pk_bf16_f32 (round-to-nearest-even, as pack_bf16x2 below): ONE instruction where the bit arithmetic of
+    // f32_to_bf16_bits is 6 -- round 6 found 10 000 such sequences in the conv epilogues' element-wise paths and 8 per lane-vector
+    // in the stand-alone fused_bias_act / upfirdn2d kernels, whose bf16 forms were slower than their fp32 forms on the same
+    // element count (profiles/r06_op_bench_bf16.json).  Same bits for every finite value; a NaN comes out as the canonical quiet NaN.
+    r.v = __builtin_bit_cast(uint16_t, (__bf16)f);
+#endif
     return r;
 }
 template <>
