@@ -327,7 +327,10 @@ def test_conv_thin_kernel(dev, dtype):
             (1, 18 * kstep, 9, 7, 3, 3, 0, False),          # 18 K-steps over 4 waves (576 channels in bf16)
             (1, 2 * kstep, 5, 20, 2, 3, 0, False),          # fewer K-steps than wavefronts; cout 2
             (2, 4 * kstep, 7, 5, 3, 1, 0, True),            # ToRGB: 1x1 + bias + up-sampled skip (residual)
-            (1, 9 * kstep, 16, 8, 1, 1, 0, False)]:
+            (1, 9 * kstep, 16, 8, 1, 1, 0, False),
+            # >= 256 tiles of 16 x 16 per image: conv_thin16_kernel (round 6; pixels split over the waves, K in one chain)
+            (1, 3 * kstep, 256, 256, 1, 3, RT, False),      # mask conv shape, whole tiles, odd number of K-steps
+            (2, 2 * kstep, 258, 262, 3, 3, 0, True)]:       # fusion_skip-like: 27 virtual channels, ragged edges, batch 2, residual
         pad = k // 2
         e_new = _conv_case(dev, dtype, N, Cin, H, W, Cout, k, 1, pad, 1, act=act, resid=resid, planar=True, seed=Cin + H)
         e_old = _conv_case(dev, dtype, N, Cin, H, W, Cout, k, 1, pad, 1, act=act, resid=resid, planar=True, seed=Cin + H,
@@ -347,7 +350,8 @@ def test_conv_thin_gate_prologue(dev, dtype):
     g = np.random.default_rng(41)
     kstep = 16 if dtype == torch.float32 else 32
     code = K.dt_code(dtype)
-    for (N, c, H, W) in ((1, 2 * kstep, 8, 8), (2, 3 * kstep, 11, 13), (1, 5 * kstep, 5, 20)):
+    for (N, c, H, W) in ((1, 2 * kstep, 8, 8), (2, 3 * kstep, 11, 13), (1, 5 * kstep, 5, 20),
+                         (2, 2 * kstep, 256, 260), (1, 3 * kstep, 258, 256)):   # (the last two: 16 x 16 tiles, conv_thin16_kernel)
         fg = g.standard_normal((N, c, H, W)).astype(np.float32)
         fe = g.standard_normal((N, c, H, W)).astype(np.float32)
         w = (g.standard_normal((1, 2 * c, 3, 3)) / math.sqrt(18 * c)).astype(np.float32)

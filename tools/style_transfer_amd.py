@@ -430,6 +430,8 @@ def main(argv=None, device=None, backend=None) -> dict:
     barrier()
     dt = time.time() - t0
     log(f"Transfer style successfully!  {n} frames in {dt:.2f} s ({n / max(dt, 1e-9):.1f} frames/s incl. I/O) -> {out_path}")
+    if dist.is_initialized() and "RANK" in os.environ and backend is None:   # launched by torch.distributed.run: leave the group cleanly
+        dist.destroy_process_group()
     return {"frames": n, "shard": (a, b), "done": done, "seconds": dt, "output": out_path, "rank": rank, "world_size": ws}
 
 

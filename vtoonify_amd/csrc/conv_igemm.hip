@@ -2198,7 +2198,7 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
         // thin outputs (cout <= 3, planar): one launch, K over the wavefronts of a workgroup, no slabs
         if ((hp == 6 || (hp == 0 && hbm == 0 && hs == 0)) && thin_eligible<T>(a)) {
             t.kind = 6;
-            t.bm = TH_TW * TH_TW;
+            t.bm = thin16_wanted(a) ? TH16 * TH16 : TH_TW * TH_TW;   // (16 x 16-pixel tiles at the large levels, conv_thin.hpp)
             t.bn = a.taps * a.coutT > 16 ? 32 : 16;
             t.splitk = 1;
             return t;

@@ -234,6 +234,198 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
     ((float*)p.out)[off] = post_act(p, v + (rs ? p.beta * rs[off] : 0.0f));
 }
 
+// ---------------------------------------------------------------------------------------
+// The same contraction on 16 x 16-pixel tiles with the PIXELS split over the wavefronts (round 6): the thin convs of the two
+// large fusion levels (128^2, 256^2: mask conv 2C -> 1 with the gate prologue, fusion_skip C + 64 -> 3).
+//
+// With several steps in flight the frame rate is set by what every kernel takes of the GPU, not by its latency
+// (profiles/r06_lanes.txt), and at those levels the 8 x 8 tiles above take the whole GPU for 63 + 41 + 29 + 15 us per step at
+// 2.0-2.5 TB/s: every tile reads a 10 x 10 patch for 8 x 8 outputs (1.56 x), each wave walks its quarter of the K steps with one
+// or two loads in flight and the four partial tiles meet in 36 KB of LDS.  Here a workgroup owns 16 x 16 outputs (18 x 18 patch:
+// 1.27 x), a wave owns every fourth pixel fragment for ALL K steps (no partial tiles: the d tile is written once), and the loads of
+// two K steps are in flight per wave.  K order: 0 .. nk-1 in one accumulator chain per output -- not the order of the 8 x 8 kernel
+// (K steps interleaved over four waves), so the choice between the two is by the per-image geometry only (launch_thin).
+// ---------------------------------------------------------------------------------------
+constexpr int TH16 = 16;
+constexpr int TH16_NW = 4;           // wavefronts of the 16 x 16 form: 6 pixel fragments each (21 of an 18 x 18 patch).  (8 waves of 3
+                                    // fragments with two K steps in flight in the gate half measured 50 / 31 us against 47 / 27.)
+
+template <typename T, int KS, int NB, bool PRO = false>
+__global__ void __launch_bounds__(TH16_NW * 64) conv_thin16_kernel(const ConvArgs p) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int KSTEP = 4 * VEC;
+    constexpr int PW = TH16 + KS - 1;                // 18 or 16
+    constexpr int NPIX = PW * PW;
+    constexpr int NF = (NPIX + 15) / 16;             // 21 or 16 pixel fragments
+    constexpr int FPW = (NF + TH16_NW - 1) / TH16_NW;   // fragments per wave: 6 or 4
+    constexpr int TAPS = KS * KS;
+    constexpr int UNR = 2;                           // K steps in flight per wave
+    __shared__ __attribute__((aligned(16))) float dt[NF * 16][16 * NB + TH_PADC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = vt_uniform(tid >> 6) & (TH16_NW - 1);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int tiles_x = (p.W + TH16 - 1) / TH16, tiles_y = (p.H + TH16 - 1) / TH16;
+    const int img = blockIdx.x / (tiles_x * tiles_y);
+    const int trem = blockIdx.x - img * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH16, x0 = (trem % tiles_x) * TH16;
+    const int ncols = TAPS * p.coutT;
+
+    const T* src = (const T*)p.src0;
+    const T* oth = (const T*)p.src1;
+    int64_t poff[FPW], qoff[PRO ? FPW : 1];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave + TH16_NW * i;            // this wave's i-th fragment
+        const int pp = f * 16 + l15;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 + py - (KS / 2), ix = x0 + px - (KS / 2);
+        const bool in = f < NF && pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[i] = in ? ((int64_t)(img * p.H + iy) * p.W + ix) * p.ld0 + q * VEC : -1;
+        if (PRO) qoff[i] = in ? ((int64_t)(img * p.H + iy) * p.W + ix) * p.ld1 + q * VEC : -1;
+    }
+    const T* wg = (const T*)p.wgt;
+    int64_t woff[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int v = b * 16 + l15;
+        const int tap = v / p.coutT, co = v - tap * p.coutT;
+        woff[b] = v < ncols ? ((int64_t)co * TAPS + tap) * p.cin + q * VEC : -1;
+    }
+    f32x4 acc[FPW][NB];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const u128 zero = u128{0u, 0u, 0u, 0u};
+    const int nk = p.cin / KSTEP;
+    auto affine = [&](u128& frag, bool ok, const float* sc, const float* sh, const u128* og) {   // (the gate prologue of the 8 x 8 kernel)
+        if (!ok) return;
+        float v[VEC];
+        unpack16<T>(frag, v);
+        if (og) {
+            float g[VEC];
+            unpack16<T>(*og, g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fabsf(v[i] - g[i]);
+        }
+        if (p.in_scale) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = v[i] * sc[i] + sh[i];
+        }
+        frag = pack16<T>(v);
+    };
+    auto table = [&](int ks, float* sc, float* sh) {
+        if (!p.in_scale) return;
+        const int so = img * p.cin + ks * KSTEP + q * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+            unpack16<float>(ld128(p.in_scale + so + i), sc + i);
+            unpack16<float>(ld128(p.in_shift + so + i), sh + i);
+        }
+    };
+    const int nk0 = (PRO && p.in_absdiff) ? p.c0 / KSTEP : nk;   // K steps that read src0 as it is
+    // ---- K steps [0, nk0): one source ----
+    for (int k0 = 0; k0 < nk0; k0 += UNR) {
+        u128 fa[UNR][FPW], fw[UNR][NB];
+        float scv[UNR][PRO ? VEC : 1], shv[UNR][PRO ? VEC : 1];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool live = k0 + u < nk0;
+            const int kb = (live ? k0 + u : k0) * KSTEP;
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) fa[u][i] = (live && poff[i] >= 0) ? ld128(src + poff[i] + kb) : zero;
+            if (PRO) table(live ? k0 + u : k0, scv[u], shv[u]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (PRO) {
+                const bool live = k0 + u < nk0;
+#pragma unroll
+                for (int i = 0; i < FPW; ++i) affine(fa[u][i], live && poff[i] >= 0, scv[u], shv[u], nullptr);
+            }
+#pragma unroll
+            for (int i = 0; i < FPW; ++i)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) Mma<T>::run(acc[i][b], fw[u][b], fa[u][i]);
+        }
+    }
+    // ---- K steps [nk0, nk): |src0 - src1| (the Fusion gate's second half) ----
+    if constexpr (PRO) {
+        constexpr int UNR2 = FPW <= 3 ? 2 : 1;   // two operands per fragment: one K step in flight at 6 fragments per wave (registers)
+        for (int k0 = nk0; k0 < nk; k0 += UNR2) {
+            u128 fa[UNR2][FPW], fo[UNR2][FPW], fw[UNR2][NB];
+            float scv[UNR2][VEC], shv[UNR2][VEC];
+#pragma unroll
+            for (int u = 0; u < UNR2; ++u) {
+                const bool live = k0 + u < nk;
+                const int ks = live ? k0 + u : k0;
+                const int kb = ks * KSTEP, kc = kb - p.c0;
+#pragma unroll
+                for (int i = 0; i < FPW; ++i) {
+                    fa[u][i] = (live && poff[i] >= 0) ? ld128(src + poff[i] + kc) : zero;
+                    fo[u][i] = (live && qoff[i] >= 0) ? ld128(oth + qoff[i] + kc) : zero;
+                }
+                table(ks, scv[u], shv[u]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) fw[u][b] = (live && woff[b] >= 0) ? ld128(wg + woff[b] + kb) : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR2; ++u) {
+                const bool live = k0 + u < nk;
+#pragma unroll
+                for (int i = 0; i < FPW; ++i) affine(fa[u][i], live && poff[i] >= 0, scv[u], shv[u], &fo[u][i]);
+#pragma unroll
+                for (int i = 0; i < FPW; ++i)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) Mma<T>::run(acc[i][b], fw[u][b], fa[u][i]);
+            }
+        }
+    }
+    // the d tile: pixel f*16 + l15, virtual channels b*16 + 4q .. +3 -- written once, by the wave that owns the fragment
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave + TH16_NW * i;
+        if (f < NF) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float v4[4] = {acc[i][b][0], acc[i][b][1], acc[i][b][2], acc[i][b][3]};
+                st128(&dt[f * 16 + l15][b * 16 + q * 4], pack16<float>(v4));
+            }
+        }
+    }
+    __syncthreads();
+    // stencil + epilogue: thread = output pixel, all of its (<= 3) channels
+    if (tid >= TH16 * TH16) return;
+    const int oy = tid / TH16, ox = tid - oy * TH16;
+    const int gy = y0 + oy, gx = x0 + ox;
+    if (gy >= p.H || gx >= p.W) return;
+    const float ga = p.gain_alpha * (p.alpha_dev ? p.alpha_dev[0] : 1.0f);
+    const int64_t HoWo = (int64_t)p.H * p.W;
+    const float* rs = (const float*)p.resid;
+    for (int co = 0; co < p.coutT; ++co) {
+        float s = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            s += dt[(oy + ky) * PW + ox + kx][tap * p.coutT + co];
+        }
+        const float v = conv_finish(p, s, p.bias ? p.bias[co] : 0.0f, ga, p.slope);
+        const int64_t off = ((int64_t)img * p.cout + co) * HoWo + (int64_t)gy * p.W + gx;
+        ((float*)p.out)[off] = post_act(p, v + (rs ? p.beta * rs[off] : 0.0f));
+    }
+}
+
+// 16 x 16 tiles from 256 tiles per IMAGE up (the 256^2 level of a 256^2 frame; at 128^2 the two forms measured the same, 29 / 15 us
+// against 31 / 16): by geometry only -- the two kernels sum K in different orders -- and only for the 3 x 3 forms
+static bool thin16_wanted(const ConvArgs& a) {
+    return a.taps == 9 && (int64_t)vt_cdiv(a.H, TH16) * vt_cdiv(a.W, TH16) >= 256;
+}
+
 template <typename T>
 int launch_thin(const ConvArgs& a, vt_stream stream) {
     ConvArgs args = a;
@@ -245,11 +437,25 @@ int launch_thin(const ConvArgs& a, vt_stream stream) {
         return VT_ERR_ARG;
     }
     const bool two = a.taps * a.coutT > 16;
-    if (a.in_scale || a.in_absdiff) {   // the loader prologue: only the Fusion gate's shape is compiled (3x3, <= 16 virtual channels)
-        if (a.taps != 9 || two) {
-            vt_set_error("vt_conv2d: in_scale / in_absdiff on a thin conv need a 3x3 kernel with 9 * cout <= 16");
-            return VT_ERR_UNSUPPORTED;
+    if ((a.in_scale || a.in_absdiff) && (a.taps != 9 || two)) {   // the loader prologue: only the Fusion gate's shape is compiled
+        vt_set_error("vt_conv2d: in_scale / in_absdiff on a thin conv need a 3x3 kernel with 9 * cout <= 16");
+        return VT_ERR_UNSUPPORTED;
+    }
+    if (thin16_wanted(a)) {
+        const unsigned b16 = (unsigned)((int64_t)a.N * vt_cdiv(a.H, TH16) * vt_cdiv(a.W, TH16));
+        if (a.in_scale || a.in_absdiff) {
+            auto k = conv_thin16_kernel<T, 3, 1, true>;
+            VT_LAUNCH(k, dim3(b16), dim3(TH16_NW * 64), stream, args);
+        } else if (two) {
+            auto k = conv_thin16_kernel<T, 3, 2>;
+            VT_LAUNCH(k, dim3(b16), dim3(TH16_NW * 64), stream, args);
+        } else {
+            auto k = conv_thin16_kernel<T, 3, 1>;
+            VT_LAUNCH(k, dim3(b16), dim3(TH16_NW * 64), stream, args);
         }
+        return vt_check_launch("vt_conv2d(thin, 16x16)");
+    }
+    if (a.in_scale || a.in_absdiff) {
         auto k = conv_thin_kernel<T, 3, 1, true>;
         VT_LAUNCH(k, dim3((unsigned)blocks), dim3(TH_NW * 64), stream, args);
     } else if (a.taps == 9 && two) {
