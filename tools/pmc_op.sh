@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes over ONE stand-alone operator call (round 6: what upfirdn2d's bf16 blur waits for).
-#   gpurun -- 'bash tools/gpu.sh TAG sh "bash tools/pmc_op.sh TAG VAR v1 v2 ..."'      (VAR: an environment switch; use X for none)
+#   gpurun -- 'bash tools/gpu.sh TAG sh "bash tools/pmc_op.sh TAG VAR v1 v2 ..."'      (VAR: an environment switch the library reads, or any unused name with one value)
 TAG=$1; VAR=$2; shift 2
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; export TMPDIR=/tmp
 PA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
