@@ -79,7 +79,7 @@ def pmc_traffic(kernel_class: str):
         tt = "bf16_t" if dt == "bf16" else "float"
         if name == "conv_fullk_kernel":
             lead = f"{name}<{tt}"
-        elif name == "conv_upblur_kernel":
+        elif name in ("conv_upblur_kernel", "conv_upflat_kernel"):
             lead = f"{name}<{tt}, {bn},"
         elif name == "conv_upblur_rows_kernel":   # (template argument: the input channel count)
             lead = f"{name}<"

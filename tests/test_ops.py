@@ -1613,7 +1613,8 @@ def test_conv_transpose_blur_kernel(dev, dtype, monkeypatch):
     fir = (np.outer(k1, k1) / 64.0 * 4.0).astype(np.float32)       # make_kernel([1,3,3,1]) * factor^2 (model.py:66,192-198)
     for N, cin, H, W, cout, hint in [(2, 2 * unit, 11, 16, 40, 32), (1, unit, 13, 3, 32, 0),
                                      (1, 5 * unit, 6, 9, 32, 16),    # 16-channel tiles, >= 4 chunks: double-buffered
-                                     (1, 2 * unit, 27, 15, 32, 32)]:  # two rows of tall tiles (44 output rows each)
+                                     (1, 2 * unit, 27, 15, 32, 32),   # two rows of tall tiles (44 output rows each)
+                                     (2, 2 * unit, 33, 40, 40, 32)]:  # 5 x 2 flat tiles (16 x 64 output pixels each)
         x = g.standard_normal((N, cin, H, W)).astype(np.float32)
         w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
         b = g.standard_normal(cout).astype(np.float32)
@@ -1627,6 +1628,7 @@ def test_conv_transpose_blur_kernel(dev, dtype, monkeypatch):
         kw = dict(src0=xt, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=2 * H, out_w=2 * W, weight=wp, cout=cout, kh=3, kw=3,
                   bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=cout, dtype=K.dt_code(dtype),
                   up_fir=T(fir, dev), tile_hint=hint)
+        monkeypatch.setenv("VT_UPBLUR_FLAT", "0")   # (the flat tiles of the deep levels have their own block below)
         code = _lib.lib().vt_conv2d_tile(ctypes.byref(K.make_conv_desc(**kw)))
         assert code // 100000000 == 5 and code % 1000 == (hint or 16), code   # few tiles: the heuristic takes 16
         K.conv2d(**kw)
@@ -1646,6 +1648,19 @@ def test_conv_transpose_blur_kernel(dev, dtype, monkeypatch):
             monkeypatch.delenv("VT_UPBLUR_TALL")
             monkeypatch.delenv("VT_UPBLUR_DB")
             assert torch.equal(out_t, out), (N, cin, H, W, cout, "tall")
+        if dtype == torch.bfloat16:      # ... and the flattened 10 x 34-quad tiles of the deep levels (conv_upblur_flat.hpp)
+            monkeypatch.setenv("VT_UPBLUR_FLAT", "1")
+            code = _lib.lib().vt_conv2d_tile(ctypes.byref(K.make_conv_desc(**{**kw, "tile_hint": 32})))
+            assert code // 100000000 == 10, code
+            out_f = torch.zeros_like(out)
+            K.conv2d(**{**kw, "out": out_f, "tile_hint": 32})
+            assert torch.equal(out_f, out), (N, cin, H, W, cout, "flat")
+            monkeypatch.setenv("VT_UPBLUR_FLAT_CN", "32" if code % 1000 == 16 else "16")   # ... of either width
+            out_f.zero_()
+            K.conv2d(**{**kw, "out": out_f, "tile_hint": 32})
+            monkeypatch.delenv("VT_UPBLUR_FLAT_CN")
+            monkeypatch.setenv("VT_UPBLUR_FLAT", "0")
+            assert torch.equal(out_f, out), (N, cin, H, W, cout, "flat, other width")
         # the polyphase form of the same layer (blur folded into four 3x3 filters)
         wpp = K.modulate_weight(T(w, dev), torch.ones(cin, device=dev), 1.0, False, fir=T(fir, dev), out_dtype=dtype)
         out2 = torch.zeros_like(out)

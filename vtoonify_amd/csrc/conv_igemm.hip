@@ -1721,6 +1721,7 @@ __device__ __forceinline__ void vt_static_for(F&& f) {
 #include "conv_upblur.hpp"
 static int device_cus();
 #include "conv_upblur_rows.hpp"
+#include "conv_upblur_flat.hpp"
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
 #include "conv_patch_chunk.hpp"
@@ -2628,6 +2629,9 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
             // the two top levels (Cin <= 128, >= 128^2 input pixels): one wave per strip, horizontal blur on the matrix cores,
             // no z tile (conv_upblur_rows.hpp).  Other bits than the tile kernels below, so the choice is by shape only.
             if (uprows_wanted<T>(a)) return launch_uprows<T>(a, stream);
+            // the deep levels (Cin >= 256): flattened 10 x 34-quad tiles, K ring of 32-channel steps (conv_upblur_flat.hpp).
+            // The bits of the tile kernels below (same K order, same blur), so the choice may depend on the batch.
+            if (upflat_wanted<T>(a)) return launch_upflat<T>(a, stream);
         }
         if constexpr (sizeof(T) == 2) {
             // single-chunk layers (the 1024^2 level) with >= 4 tiles per CU: persistent 8-wave workgroups on 16 x 16-quad tiles
@@ -2933,6 +2937,7 @@ extern "C" int vt_conv2d_tile(const vt_conv_desc* d) {
     if (kind == 5 && d->dtype == VT_BF16) {   // 9 = the strip-marching form of the top up-sampling convs (conv_upblur_rows.hpp)
         UpblurArgs ub;
         if (uprows_wanted<bf16_t>(a) && upblur_eligible<bf16_t>(a, ub, 2, UR_OW)) kind = 9, bm = UR_OW, bn = 32;
+        else if (upflat_wanted<bf16_t>(a) && upblur_eligible<bf16_t>(a, ub, 16, 64)) kind = 10, bm = 10 * UF_PW, bn = upflat_cn(a);   // conv_upblur_flat.hpp
     }
     return kind * 100000000 + t.splitk * 1000000 + bm * 1000 + bn;
 }

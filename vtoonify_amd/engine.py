@@ -723,7 +723,8 @@ class VToonifyEngine:
             kind, sk, bm, bn = tile // 100000000, (tile // 1000000) % 100, (tile // 1000) % 1000, tile % 1000
             kname = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_igemm_glds_kernel",
                      3: "conv3x3_c32_kernel", 4: "conv_fullk_kernel", 5: "conv_upblur_kernel",
-                     6: "conv_thin_kernel", 7: "conv_patchs2_kernel", 8: "conv_fullkw_kernel", 9: "conv_upblur_rows_kernel"}[kind]
+                     6: "conv_thin_kernel", 7: "conv_patchs2_kernel", 8: "conv_fullkw_kernel", 9: "conv_upblur_rows_kernel",
+                     10: "conv_upflat_kernel"}[kind]
             info["kernel"] = f"{kname}<{tname},{bm}x{bn}>"
             info["splitk"] = sk
             if sk > 1 and self.lib.vt_conv2d_splitk_mode(C.byref(d)) == 2:
