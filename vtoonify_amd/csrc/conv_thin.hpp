@@ -47,6 +47,19 @@ static bool thin_eligible(const ConvArgs& a) {
 // (p.in_absdiff) and / or every in-image value goes through x' = x * in_scale[n][c] + in_shift[n][c], rounded to T like a
 // stored tensor -- the vt_affine_apply launch and its 2C-channel normalised copy (268 MB per 4-frame step at the 256^2 level)
 // fold into the conv that reads them.  Bit-identical to the two launches (same operations in the same order).
+// Workgroup -> tile: consecutive workgroups go round the 8 XCDs, so tile = blockIdx gave horizontally adjacent tiles -- which share
+// two of their 10 (18) patch columns -- to different L2s.  Here every XCD takes one contiguous run of tiles in row-major order (8
+// rows of 16 tiles at the 256^2 level): the halos of a run meet in its L2.  Fabric bytes per 4-frame launch at that level
+// (rocprofv3 --pmc, calls r06s -> r06ab): mask conv 258 -> 220 MB for 134 MB of input, fusion_skip 121 -> 107 MB; the time did
+// not move (47 / 28 us): these kernels are not bound by the fabric.  (Neither by their branches: the same loop with range-checked
+// buffer loads instead of `cond ? load : zero` -- one basic block -- measured 47 / 39 us, call r06ac, and was dropped.)
+__device__ __forceinline__ int thin_tile_of_block() {
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <typename T, int KS, int NB, bool PRO = false>   // KS = 3 (3x3, pad 1) or 1 (1x1); NB = weight fragments (16 virtual channels each)
 __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p) {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -63,8 +76,9 @@ __global__ void __launch_bounds__(TH_NW * 64) conv_thin_kernel(const ConvArgs p)
     const int wave = vt_uniform(tid >> 6) & (TH_NW - 1);
     const int q = lane >> 4, l15 = lane & 15;
     const int tiles_x = (p.W + TH_TW - 1) / TH_TW, tiles_y = (p.H + TH_TW - 1) / TH_TW;
-    const int img = blockIdx.x / (tiles_x * tiles_y);
-    const int trem = blockIdx.x - img * (tiles_x * tiles_y);
+    const int tile = thin_tile_of_block();
+    const int img = tile / (tiles_x * tiles_y);
+    const int trem = tile - img * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH_TW, x0 = (trem % tiles_x) * TH_TW;
     const int ncols = TAPS * p.coutT;
 
@@ -267,8 +281,9 @@ __global__ void __launch_bounds__(TH16_NW * 64) conv_thin16_kernel(const ConvArg
     const int wave = vt_uniform(tid >> 6) & (TH16_NW - 1);
     const int q = lane >> 4, l15 = lane & 15;
     const int tiles_x = (p.W + TH16 - 1) / TH16, tiles_y = (p.H + TH16 - 1) / TH16;
-    const int img = blockIdx.x / (tiles_x * tiles_y);
-    const int trem = blockIdx.x - img * (tiles_x * tiles_y);
+    const int tile = thin_tile_of_block();
+    const int img = tile / (tiles_x * tiles_y);
+    const int trem = tile - img * (tiles_x * tiles_y);
     const int y0 = (trem / tiles_x) * TH16, x0 = (trem % tiles_x) * TH16;
     const int ncols = TAPS * p.coutT;
 

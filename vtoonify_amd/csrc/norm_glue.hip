@@ -98,22 +98,23 @@ instnorm_partial_kernel(StatRec* __restrict__ part, const T* __restrict__ x, int
                 red[(tid * VEC + i) * 2 + 1] = half ? s2b[i] : s2a[i];
             }
             __syncthreads();
-            // thread (prow == 0) of each channel-vector folds the pixel rows in order
+            // fold the pixel rows in order r = 0 .. rows - 1, one (channel, sum) per thread: cpar * VEC * 2 sums over the 256
+            // threads.  (Round 6: the thread of pixel row 0 used to fold all 2 * VEC sums of its channel vector by itself --
+            // 2 * VEC * rows dependent LDS reads on 1 thread in 16, 8-16 us of tail per chunk at the 128 / 256-channel levels.)
+            // The same additions in the same order: the same records.
+            StatRec* rec0 = part + ((int64_t)img * chunks + chunk) * ctot + half * c + cbase * VEC;
+            const int nsum = cpar * VEC * 2;
+            for (int o = tid; o < nsum; o += 256) {
+                const int which = o & 1, ch = o >> 1;             // ch = cv0' * VEC + i inside this channel block
+                if (cbase * VEC + ch < c) {
+                    float a = 0.0f;
+                    for (int r = 0; r < rows; ++r) a += red[((r * cpar) * VEC + ch) * 2 + which];
+                    (which ? rec0[ch].s2 : rec0[ch].s1) = a;
+                }
+            }
             if (on && prow == 0) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float a1 = 0.0f, a2 = 0.0f;
-                    for (int r = 0; r < rows; ++r) {
-                        const int t = r * cpar + cv0;
-                        a1 += red[(t * VEC + i) * 2 + 0];
-                        a2 += red[(t * VEC + i) * 2 + 1];
-                    }
-                    StatRec rec;
-                    rec.x0 = half ? x0b[i] : x0a[i];
-                    rec.s1 = a1;
-                    rec.s2 = a2;
-                    part[((int64_t)img * chunks + chunk) * ctot + half * c + cv * VEC + i] = rec;
-                }
+                for (int i = 0; i < VEC; ++i) rec0[cv0 * VEC + i].x0 = half ? x0b[i] : x0a[i];
             }
         }
     }
