@@ -116,7 +116,8 @@ DOCUMENTED_SWITCHES = {
     "VTOONIFY_AMD_DTYPE", "VT_BATCH_EXACT", "VT_MAX_PLANS", "VT_TILE_HINTS", "VT_GRAPH_FIRST", "VT_STYLE_GATE", "VT_PATCH_PIPE",
     "VT_FULLKW", "VT_RAFT_GRAPH",
     # test hooks: force a kernel form that the heuristics only choose at sizes a CPU-emulated test cannot afford
-    "VT_C32_BLOCKS", "VT_UPBLUR_WGS", "VT_PATCHW_WGS", "VT_UPBLUR_TALL", "VT_UPBLUR_P8", "VT_UPBLUR_DB", "VT_UPBLUR_ROWS", "VT_FULLKW_MIN_G", "VT_FULLKW_G",
+    "VT_C32_BLOCKS", "VT_UPBLUR_WGS", "VT_PATCHW_WGS", "VT_UPBLUR_TALL", "VT_UPBLUR_P8", "VT_UPBLUR_DB", "VT_UPBLUR_ROWS", "VT_UPBLUR_FLAT", "VT_UPBLUR_FLAT_CN",
+    "VT_FULLKW_MIN_G", "VT_FULLKW_G",
     "VT_SPLITK_IN_LAUNCH", "VT_GATE_LOADER",
 }
 

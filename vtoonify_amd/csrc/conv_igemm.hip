@@ -1531,7 +1531,8 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     constexpr int PH = TH + 2, PW = TW + 2, PROWS = PH * PW;   // 324 patch pixels
     constexpr int PA = ((PROWS + 15) / 16 + 3) / 4;              // 16-pixel loads per wave per tile: 6
     constexpr int A_BYTES = PA * 4 * 1024;                       // 24 KB per buffer
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_BYTES];
+    constexpr int NBUF = 3;                                      // patches in flight: this tile's + two ahead (72 KB: two workgroups per CU)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * A_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1611,12 +1612,20 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     issue(tile, 0);
+    if (tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x, 1);
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) {
-            issue(next, buf ^ 1);
-            vt_glds_wait_n<PA>();      // this tile's patch has landed, the next one may be in flight
+        // Round 6: TWO patches ahead (a CU streams from HBM at ~12 B/clk, profiles/r06_ingest_probe.txt: one 21 KB patch per
+        // workgroup in flight does not cover the latency at that rate).  The patch of tile t + 2 goes into the buffer tile t - 1
+        // was read from (every wave is past the barrier that ended t - 1).  vmcnt counts everything in order -- patches, the
+        // skip loads, the stores: the 2 PA newest operations are the patch just issued and >= PA of what followed the patch of
+        // t + 1 (itself, the stores and skip loads of t - 1), so this tile's patch is older than all of them.
+        const int next2 = tile + 2 * (int)gridDim.x;
+        if (next2 < ntiles) {
+            issue(next2, buf == 0 ? 2 : buf - 1);
+            vt_glds_wait_n<2 * PA>();
+        } else if (tile + (int)gridDim.x < ntiles) {
+            vt_glds_wait_n<PA>();      // (the last but one: only the next patch is younger)
         } else {
             vt_glds_wait_n<0>();
         }
@@ -1702,7 +1711,7 @@ conv3x3_c32_kernel(const ConvArgs p, const GldsArgs g) {
             }
         }
         vt_lds_barrier();   // every wave is done reading `buf` before the next issue overwrites it
-        buf ^= 1;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
     }
 }
 
