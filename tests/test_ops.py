@@ -743,40 +743,6 @@ def test_conv_patch_chunk_equals_pipelined(dev, monkeypatch):
         assert rel_err(got.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy(), want) < 8e-3
 
 
-def test_conv_dilation4_on_flat_blocks(dev, monkeypatch):
-    """conv_flat8_kernel (csrc/conv_patch_flat.hpp, round 6): the dilation-4 convs of the AdaResBlocks (model/vtoonify.py:201-207)
-    as 16 dense convs on the 4 x 4 sub-images of the plane, four 8 x 8 blocks of a sub-image per workgroup, flat patches of pitch 10.
-    Against the oracle's dilated conv: the trunk's own shape (4 frames of 32 x 32), sub-images smaller than a block (18 x 32:
-    config3's trunk), larger than one and ragged (45 x 50), a unit count that is not a multiple of 4, a ragged channel tile, the
-    lean epilogue and the general one (residual with alpha / beta); and against the whole-K kernel the same launch takes otherwise."""
-    dtype = torch.bfloat16
-    g = np.random.default_rng(67)
-    for N, cin, H, W, cout, resid in ((4, 128, 32, 32, 64, False), (1, 64, 18, 32, 40, True), (1, 96, 45, 50, 32, True),
-                                      (3, 64, 8, 8, 32, False)):
-        x = g.standard_normal((N, cin, H, W)).astype(np.float32)
-        w = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
-        b = g.standard_normal(cout).astype(np.float32)
-        xa = K.nchw_to_nhwc(T(x, dev), dtype)
-        wp = K.pack_conv_weight(T(w, dev), out_dtype=dtype)
-        ldo = (cout + 7) // 8 * 8
-        r = K.nchw_to_nhwc(T(g.standard_normal((N, cout, H, W)).astype(np.float32), dev), dtype, ld_out=ldo) if resid else None
-
-        def run(hint):
-            out = torch.zeros((N, H, W, ldo), dtype=dtype, device=dev)
-            kw = dict(alpha=0.5, beta=0.25, resid=r, ld_res=ldo) if resid else {}
-            K.conv2d(src0=xa, c0=cin, ld0=cin, n=N, h=H, w=W, out_h=H, out_w=W, weight=wp, cout=cout, kh=3, kw=3, pad=4, dil=4,
-                     bias=T(b, dev), act=K.ACT_LRELU, gain=2 ** 0.5, out=out, ld_out=ldo, dtype=K.dt_code(dtype), tile_hint=hint, **kw)
-            return out.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy()
-        got = run(P + 256032)
-        xq = xa.float().cpu().permute(0, 3, 1, 2).numpy()
-        wq = wp.float().cpu().numpy().reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
-        want = O.leaky_relu(O.conv2d(xq, wq, b, 1, 4, 4), 0.2) * np.float32(2 ** 0.5)
-        if resid:
-            want = want * 0.5 + 0.25 * r.float().cpu().permute(0, 3, 1, 2)[:, :cout].numpy()
-        assert rel_err(got, want) < 8e-3, (N, cin, H, W, cout, resid)
-        assert rel_err(got, run(0)) < 8e-3, (N, cin, H, W, cout, resid, "other plan")
-
-
 def test_conv_stride2_by_input_parity(dev):
     """conv_patchs2_kernel (csrc/conv_patch_s2.hpp, round 6): the encoder's stride-2 3x3 convs (model/vtoonify.py:167-176) as four
     dense convs on the parity sub-images of the input, patch-resident.  Against the oracle: one and several chunks, ragged tiles

@@ -1734,7 +1734,6 @@ static int device_cus();
 #include "conv_thin.hpp"
 #include "conv_patch_pipe.hpp"
 #include "conv_patch_chunk.hpp"
-#include "conv_patch_flat.hpp"
 #include "conv_patch_s2.hpp"
 #include "conv_patch_resident.hpp"
 #include "conv_patch_persist.hpp"
@@ -2277,9 +2276,9 @@ static TilePlan choose_plan(const ConvArgs& a, int hint, int64_t ws_floats_avail
             // (round 5: the dilation-2 convs of the AdaResBlocks too -- conv_patch_pipe.hpp, DIL = 2: 32.3 -> 2x us at 4 frames;
             // only in the pipelined form, so not under VT_PATCH_PIPE=0)
             const char* ppe = getenv("VT_PATCH_PIPE");
-            // (round 6: dilation 4 too -- conv_patch_flat.hpp; it has no tap-granular twin either)
-            const bool dil_ok = a.dil == 1 || (a.dil == 2 && !(ppe && ppe[0] == '0') && !a.x3) ||
-                                (a.dil == 4 && !(ppe && ppe[0] == '0') && !a.x3 && flat8_eligible<T>(a));
+            // (round 6: dilation 4 on flat 8 x 8 blocks of its 16 sub-images was built and measured -- 30.3 us against the 29.1 of the
+            // weight-stationary kernel, same box, profiles/r06_ab_flat8_c32.txt -- and removed: DESIGN.md 4.1u)
+            const bool dil_ok = a.dil == 1 || (a.dil == 2 && !(ppe && ppe[0] == '0') && !a.x3);
             const bool batch_patch32 = sizeof(T) == 2 && !hinted && hbm == 0 && hp == 0 && a.N > 1 && dil_ok && m1 <= 2304 &&
                                        a.coutT >= 128 && !a.tile_stats && !a.in_tile_stats && !a.stats_part &&
                                        (int64_t)a.N * ptiles(16, 32) >= 256 && !batch_exact() && patch_eligible<T>(a, g);
@@ -2562,44 +2561,6 @@ int launch_patchc(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
     return launch_reduce<T>(args, stream);
 }
 
-// dilation 4 on flat 8 x 8 blocks of the sub-images (conv_patch_flat.hpp)
-template <typename T>
-int launch_flat8(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
-    constexpr int DIL = 4, BN = 32;
-    if (!flat8_eligible<T>(a)) {
-        vt_set_error("vt_conv2d: no compiled patch tile 256x32 for this dilation-4 convolution");
-        return VT_ERR_UNSUPPORTED;
-    }
-    Flat8Args f;
-    f.nby = vt_cdiv(vt_cdiv(a.Ho, DIL), F8_SIDE);
-    f.nbx = vt_cdiv(vt_cdiv(a.Wo, DIL), F8_SIDE);
-    f.units = a.N * DIL * DIL * f.nby * f.nbx;
-    ConvArgs args = a;
-    args.slab_perm = 1;
-    args.tiles_n = vt_cdiv(a.coutT, BN);
-    args.tiles_m = vt_cdiv(f.units, 4);
-    args.splitk = 1;
-    args.kps = a.cin / 64;
-    split_mode(args);
-    const int64_t blocks = (int64_t)args.tiles_m * args.tiles_n;
-    if (blocks >= ((int64_t)1 << 31)) {
-        vt_set_error("vt_conv2d: too many tiles");
-        return VT_ERR_ARG;
-    }
-    xcd_block(args, blocks, (int64_t)4 * F8_PITCH * F8_PITCH * a.cin * 2, (int64_t)BN * a.K * 2);
-    if constexpr (sizeof(T) == 2 && !is_x3<T>::value) {
-        if (conv_lean<T>(args)) {
-            auto k = conv_flat8_kernel<T, BN, 1, DIL>;
-            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g, f);
-        } else {
-            auto k = conv_flat8_kernel<T, BN, 0, DIL>;
-            VT_LAUNCH(k, dim3((unsigned)blocks), dim3(256), stream, args, g, f);
-        }
-        return vt_check_launch("vt_conv2d(patch, flat 8x8 blocks)");
-    }
-    return VT_ERR_UNSUPPORTED;
-}
-
 // weights-resident persistent form (conv_patch_resident.hpp): one chunk of K, one channel tile, no split
 template <typename T, int TH, int BN>
 int launch_patchw(const ConvArgs& a, const GldsArgs& g, vt_stream stream) {
@@ -2817,7 +2778,6 @@ int dispatch(const ConvArgs& a0, int hint, int64_t ws_floats, vt_stream stream) 
                 if (pipe && !(e && e[0] == '1') && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchc<T>(a, g, stream);
                 if (pipe && !(e && e[0] == '1') && a.dil == 2 && t.bm == 256 && t.bn == 32 && !a.stats_part)
                     return launch_patchc<T, 2>(a, g, stream);
-                if (a.dil == 4 && t.bm == 256 && t.bn == 32) return launch_flat8<T>(a, g, stream);
             }
             if (pipe && a.dil == 1 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 8>(a, g, stream);
             if (pipe && a.dil == 2 && t.bm == 256 && t.bn == 32) return launch_patchp<T, 16, 32, 8, 1, 6, 0, 2>(a, g, stream);
