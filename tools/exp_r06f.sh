@@ -1,6 +1,7 @@
-# Same-box A/B of the whole 4-frame step: the library of commit 02d4381 (the END OF ROUND 5)
-# XCD-contiguous thin convs, the parallel row fold and the c32 ring) against this tree's, three alternations.
-# -> profiles/r06_ab_step.txt
+# Same-box A/B of the whole 4-frame step: the library of commit 02d4381 (the END OF ROUND 5) against this tree's, three
+# alternations.  The other build: git worktree add /tmp/wt 02d4381; (cd /tmp/wt; python -m vtoonify_amd.build); copy its
+# vtoonify_amd/lib/libvtoonify_amd.so to gpurun_ab/libvt_02d4381.so (git-ignored, travels with the tree).
+# -> profiles/r06_ab_round.txt
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do
   for L in gpurun_ab/libvt_02d4381.so ""; do
