@@ -51,3 +51,7 @@ if __name__ == "__main__":
     for G in ([0, 2, 3, 1], [0, 2, 0, 2]):
         print(f"c32 kernel, 16 consecutive 64-B rows from any start, slot ^ G[(row >> 2) & 3], G = {G}:",
               fragment_reads(64, lambda l: l, lambda r: G[(r >> 2) & 3], 4, [0], range(0, 400)), "-way")
+    # conv_upflat_kernel (conv_upblur_flat.hpp): 64-byte rows, pixel fragments from any start, weight fragments 16-aligned
+    for name, sw in (("slot ^ ((row >> 2) & 3)  [first build]", lambda r: (r >> 2) & 3), ("slot ^ 2 ((row >> 2) & 1)", lambda r: ((r >> 2) & 1) << 1)):
+        print(f"flat up-sampling tiles, 16 consecutive 64-B rows from any start, {name}:",
+              fragment_reads(64, lambda l: l, sw, 4, [0], range(0, 450)), "-way")

@@ -82,10 +82,12 @@ conv_upflat_kernel(const ConvArgs p, const UpblurArgs g) {
     const int I0 = u0 / 2, J0 = v0 / 2;
 
     // ---- loader: lane l of a piece = row l >> 2 of its 16 rows, physical 16-byte slot l & 3 of the 64-byte row; the logical
-    // slot (channels 8 s .. 8 s + 7 of the step) of physical slot ps of row r is ps ^ ((r >> 2) & 3): a fragment read -- 16
-    // consecutive rows, lane group q at slot q ^ ((r >> 2) & 3) -- touches every bank once.
+    // slot (channels 8 s .. 8 s + 7 of the step) of physical slot ps of row r is ps ^ 2 ((r >> 2) & 1) -- conv3x3_c32_kernel's
+    // swizzle G = {0, 2, 0, 2}: conflict-free for gfx950's ds_read_b128 lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31})
+    // over 16 consecutive rows from ANY start (tools/lds_bank_check.py).  The first build used ps ^ ((r >> 2) & 3), which is
+    // conflict-free for CONTIGUOUS 16-lane groups and 2-way for the real ones: every fragment read took two LDS passes.
     const int lrow = lane >> 2;
-    const int jj = (lane & 3) ^ ((lane >> 4) & 3);
+    const int jj = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     uint32_t ldo[PL];
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
@@ -129,9 +131,9 @@ conv_upflat_kernel(const ConvArgs p, const UpblurArgs g) {
         for (int sh = 0; sh < 4; ++sh) {
             const int di = sh >> 1, dj = sh & 1;
             const int pr = (m * NW + wave) * 16 + l15 + 1 + (1 - di) * PW - dj;
-            aoff[m][sh] = (uint32_t)(pr * 64 + ((q ^ ((pr >> 2) & 3)) << 4));
+            aoff[m][sh] = (uint32_t)(pr * 64 + ((q ^ (((pr >> 2) & 1) << 1)) << 4));
         }
-    const uint32_t boff = (uint32_t)(A_BYTES + l15 * 64 + ((q ^ ((l15 >> 2) & 3)) << 4));
+    const uint32_t boff = (uint32_t)(A_BYTES + l15 * 64 + ((q ^ (((l15 >> 2) & 1) << 1)) << 4));
 
     f32x4 acc[4][MF][TN];
 #pragma unroll
